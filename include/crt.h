@@ -1,0 +1,168 @@
+/* include/crt.h -- C ABI of the MI355X-native render path (libcrt_amd.so).
+ *
+ * Drop-in boundary for boonemiller/CudaRayTracer's per-pixel render path.  The reference has no
+ * plugin system: its boundary is four free C++ functions plus three POD classes.
+ * Each entry point below names the reference interface it replaces.  Plain pointers and sizes
+ * only; every function returns 0 on success or a negative crt_status; no exceptions cross the
+ * boundary.  One context per device; calls on one context are serialised by the caller.
+ * Thin C++ wrappers that keep the reference's own names (startRayTracing, constructTree,
+ * refitTree, freeTree, loadOBJ) live in cudaraytracer_amd/csrc/compat/.
+ */
+#ifndef CRT_H
+#define CRT_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRT_MAX_LIGHTS 8
+#define CRT_MAX_PRIMS ((1 << 25) - 64)
+
+typedef enum crt_status {
+    CRT_OK = 0,
+    CRT_ERR_ARG = -1,        /* bad argument / size out of range */
+    CRT_ERR_STATE = -2,      /* call order: e.g. render before crt_bvh_build */
+    CRT_ERR_HIP = -3,        /* a HIP runtime call failed: see crt_last_error */
+    CRT_ERR_NOMEM = -4,
+    CRT_ERR_IO = -5,
+    CRT_ERR_BUILD = -6       /* BVH build failed (e.g. the reference's runaway recursion case) */
+} crt_status;
+
+/* POD mirror of class SceneObject (SceneObjects.hpp:30-52): geometry + material + animation
+ * state.  `type` replaces the sphere/triangle bools; `center` (set but never read by the render
+ * path) is dropped. */
+typedef struct crt_prim {
+    int32_t type;            /* 0 = sphere, 1 = triangle */
+    int32_t objNum;          /* app-assigned, not an ID; carried, never read */
+    float position[3];
+    float radius;
+    float v1[3], v2[3], v3[3];
+    float v1Norm[3], v2Norm[3], v3Norm[3];
+    float ambient[3], diffuse[3], specular[3], reflective[3];
+    float shininess;
+    float direction[3];      /* sphere animation (main.cu:558-572) */
+    float speed;
+} crt_prim;
+
+/* POD mirror of class Light (SceneObjects.hpp:16-28). */
+typedef struct crt_light {
+    float color[3];
+    float direction[3];
+    int32_t point;           /* non-zero: point light (Ray.cu:604-632), else directional (Ray.cu:633-658) */
+    float constantTerm, linearTerm, quadraticTerm;
+    float position[3];
+    int32_t area;            /* carried; area lights are commented out in the reference (Ray.cu:563-603) */
+    float radius;
+} crt_light;
+
+/* startRayTracing's camera arguments (Ray.hpp:35): position and look-at point. */
+typedef struct crt_camera {
+    float position[3];
+    float target[3];         /* the reference calls this "cameraDirection"; it is a look-at point (main.cu:459) */
+} crt_camera;
+
+/* The reference's knobs are globals and literals (Ray.cu:25-28, main.cu:141-142); defaults from
+ * crt_params_default() equal them. */
+typedef struct crt_params {
+    int32_t width, height;   /* 720 x 360 */
+    int32_t bounces;         /* numBounces = 2: passes = 1 primary + (bounces-1) reflections (Ray.cu:715) */
+    int32_t spp;             /* 1; n*n stratified samples when a perfect square > 1 (extension) */
+    int32_t tile_w, tile_h;  /* image tile for sharding, default 32 x 32 */
+    int32_t rank, nranks;    /* this context renders tiles t with crt_tile_owner(t, nranks) == rank; 0, 1 */
+    int32_t sort_rays;       /* 0/1: bin secondary rays by origin cell + direction octant between bounces */
+    int32_t reserved[7];
+} crt_params;
+
+typedef struct crt_stats {
+    uint64_t rays_primary, rays_shadow, rays_reflect;   /* traversals issued by the last crt_render* call */
+    uint64_t box_tests, tri_tests, sph_tests;            /* filled only when crt_set_counting(ctx,1) */
+    double ms_total;         /* device time of the last crt_render* call (HIP events on the context's stream) */
+    double ms_trace, ms_shade, ms_other;
+    double ms_trace_nearest; /* summed duration of the nearest-hit traversal launches (dominant kernel) */
+    int32_t launches_trace_nearest;
+    int32_t nodes, prims, depth, leaves;
+    double ms_build_host, ms_refit;
+    uint64_t scene_bytes;    /* packed scene + BVH bytes resident in HBM */
+} crt_stats;
+
+typedef struct crt_ctx crt_ctx;
+
+/* ---- context ---- */
+crt_ctx* crt_create(int device, int* err);
+void crt_destroy(crt_ctx*);
+const char* crt_last_error(crt_ctx*);
+void crt_params_default(crt_params*);
+int crt_set_counting(crt_ctx*, int on);   /* per-ray test counters for the algorithmic-bytes figure (slower) */
+
+/* ---- scene: replaces the app-side std::vector<SceneObject*> / std::vector<Light> (main.cu:230-321,
+ *      464-488) that startRayTracing receives (Ray.cu:665) ---- */
+int crt_scene_set(crt_ctx*, const crt_prim* prims, int n);
+int crt_scene_update(crt_ctx*, const crt_prim* prims, int n);   /* moved geometry; same count and order */
+int crt_lights_set(crt_ctx*, const crt_light* lights, int n);
+
+/* ---- BVH: replaces newBuild+constructTree (main.cu:33-136, bvh.cu:12-273), refitTree
+ *      (bvh.cu:288-400) and freeTree (bvh.cu:274-286) ---- */
+#define CRT_BVH_WIDE 0       /* binned-SAH tree collapsed to 4-wide nodes, <=4 primitives per leaf */
+#define CRT_BVH_REFERENCE 1  /* the reference's topology (mean-centroid split, <=64 per leaf) in the same node format */
+int crt_bvh_build(crt_ctx*, int mode);
+#define CRT_REFIT_TIGHT 0
+#define CRT_REFIT_GROW 1     /* boxes only grow, as refitTree does */
+int crt_bvh_refit(crt_ctx*, int grow_only);
+int crt_bvh_free(crt_ctx*);
+/* Rank of every primitive in the reference's leaf order (DFS, left first): ties in t resolve to
+ * the lower rank, as the strict '<' at Ray.cu:199,216 does.  out[n] indexed by scene index. */
+int crt_bvh_reference_order(crt_ctx*, int32_t* rank_out, int n);
+/* Node boxes after build/refit, for parity checks of the refit kernel: 6 floats per stored child
+ * box in node order (minX,maxX,minY,maxY,minZ,maxZ), plus the root box first. */
+int crt_bvh_dump(crt_ctx*, int32_t* nnodes, float* root_box6, float* child_boxes /* nnodes*4*6 */,
+                 uint32_t* child_links /* nnodes*4 */, int cap_nodes);
+
+/* ---- render: replaces startRayTracing (Ray.hpp:35, Ray.cu:665-742).  bgr_out is the caller's
+ *      width*height*3 buffer, BGR, row 0 = bottom scanline (Ray.cu:724-731). ---- */
+int crt_render(crt_ctx*, const crt_camera*, const crt_params*, unsigned char* bgr_out_host);
+/* same, leaving the frame in HBM: dev_bgr (width*height*3 device bytes) may be NULL to use the
+ * context's own buffer; only this rank's tiles are written. */
+int crt_render_device(crt_ctx*, const crt_camera*, const crt_params*, void* dev_bgr);
+/* float colour (RGB, before Ray.cu:724-731) and per-bounce nearest-hit ids/t of the last render,
+ * for parity tests.  ids: scene index, -2-k for wall k, -1 none.  Enabled by crt_set_capture. */
+int crt_set_capture(crt_ctx*, int on);
+int crt_get_capture(crt_ctx*, int bounce, int32_t* ids, float* ts, int npixels);
+int crt_get_color(crt_ctx*, float* rgb_f32, int npixels);
+
+/* ---- nearest-hit parity hook (no counterpart in the reference, which never exposes ids or t) ---- */
+int crt_trace(crt_ctx*, const float* org_dir /* 6n host floats */, int n, int32_t* prim_out, float* t_out);
+/* shadow predicate of Ray.cu:650-656 for directional lights: out[i]=1 iff a hit exists and the
+ * nearest hit has t > 1e-9 */
+int crt_trace_shadow(crt_ctx*, const float* org_dir, int n, uint8_t* shadowed_out);
+
+/* ---- multi-GPU plumbing: the packed scene + BVH is one device blob that the host layer
+ *      broadcasts (RCCL) and imports on the other ranks ---- */
+int crt_blob_size(crt_ctx*, size_t* bytes);
+int crt_blob_device_ptr(crt_ctx*, void** dev_ptr);
+int crt_blob_import_device(crt_ctx*, const void* dev_ptr, size_t bytes);   /* copies; D2D */
+int crt_tile_owner(int tile_index, int nranks);
+/* number of tiles this rank owns and their pixel count; tile list in owned order */
+int crt_tiles_owned(const crt_params*, int32_t* ntiles, int64_t* npixels, int32_t* tile_ids, int cap);
+/* pack this rank's tiles of dev_bgr tile-major into dev_packed (npixels*3 bytes) and back */
+int crt_tiles_pack(crt_ctx*, const crt_params*, const void* dev_bgr, void* dev_packed);
+int crt_tiles_unpack(crt_ctx*, const crt_params*, int src_rank, const void* dev_packed, void* dev_bgr);
+
+int crt_get_stats(crt_ctx*, crt_stats*);
+int crt_sync(crt_ctx*);
+
+/* ---- host-side scene layer (replaces objloader.cpp:20-112, the scene literals of
+ *      main.cu:230-321 and the animation step main.cu:545-573) ---- */
+int crt_load_obj(const char* path, float* verts3, float* norms3, int max_corners);   /* returns corner count */
+int crt_scene_teapot(const char* obj_path, int with_sphere, crt_prim* out, int cap);  /* returns prim count */
+int crt_scene_spheres(int n, uint32_t seed, crt_prim* out);
+int crt_scene_soup(int ntris, uint32_t seed, crt_prim* out);
+int crt_lights_default(crt_light* out2);                                              /* l1, l3 of main.cu:465-488 */
+void crt_camera_default(crt_camera*);                                                  /* main.cu:459,508 */
+int crt_animate_host(crt_prim* prims, int n);                                          /* main.cu:545-573 */
+int crt_write_bmp(const char* path, const unsigned char* bgr, int width, int height); /* headless output */
+
+#ifdef __cplusplus
+}
+#endif
+#endif
