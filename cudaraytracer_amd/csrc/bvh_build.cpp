@@ -1,0 +1,394 @@
+/* bvh_build.cpp -- see bvh_build.h.  Compiled with -ffp-contract=off: the reference-topology
+ * builder must reproduce the reference's float comparisons (bvh.cu:58-68, 205-253). */
+#include "bvh_build.h"
+#include <algorithm>
+#include <limits>
+#include <cmath>
+#include <cstring>
+#include <thread>
+#include <functional>
+
+namespace crt {
+
+namespace {
+
+constexpr float kFmax = std::numeric_limits<float>::max();
+constexpr float kFminPos = std::numeric_limits<float>::min();   /* smallest positive: the reference's max-init */
+
+struct Centroid { float c[3]; };
+
+/* sphere centre / per-axis vertex average exactly as bvh.cu:61-66,130 */
+inline Centroid centroid_of(const crt_prim& o) {
+    Centroid r;
+    if (o.type == 0) { r.c[0] = o.position[0]; r.c[1] = o.position[1]; r.c[2] = o.position[2]; }
+    else for (int a = 0; a < 3; a++) r.c[a] = (o.v1[a] + o.v2[a] + o.v3[a]) / 3.0f;
+    return r;
+}
+
+/* strict grow updates of main.cu:45-104 / bvh.cu:70-129 / bvh.cu:301-360 */
+inline void grow(RefNode& n, const crt_prim& o) {
+    if (o.type == 0) {
+        float lo[3] = {o.position[0] - o.radius, o.position[1] - o.radius, o.position[2] - o.radius};
+        float hi[3] = {o.position[0] + o.radius, o.position[1] + o.radius, o.position[2] + o.radius};
+        if (lo[0] < n.minX) n.minX = lo[0];
+        if (lo[1] < n.minY) n.minY = lo[1];
+        if (lo[2] < n.minZ) n.minZ = lo[2];
+        if (hi[0] > n.maxX) n.maxX = hi[0];
+        if (hi[1] > n.maxY) n.maxY = hi[1];
+        if (hi[2] > n.maxZ) n.maxZ = hi[2];
+    } else if (o.type == 1) {
+        const float* vs[3] = {o.v1, o.v2, o.v3};
+        for (const float* v : vs) {
+            if (v[0] < n.minX) n.minX = v[0];
+            if (v[1] < n.minY) n.minY = v[1];
+            if (v[2] < n.minZ) n.minZ = v[2];
+            if (v[0] > n.maxX) n.maxX = v[0];
+            if (v[1] > n.maxY) n.maxY = v[1];
+            if (v[2] > n.maxZ) n.maxZ = v[2];
+        }
+    }
+}
+inline void box_reset(RefNode& n) {
+    n.maxX = n.maxY = n.maxZ = kFminPos;
+    n.minX = n.minY = n.minZ = kFmax;
+}
+/* bvh.cu:205-253: strict comparisons; on a tie nothing is assigned (fields stay 0) */
+inline void choose_axis(RefNode& n, const float mid[3]) {
+    float ex = n.maxX - n.minX, ey = n.maxY - n.minY, ez = n.maxZ - n.minZ;
+    if (ex > ey && ex > ez) { n.longestAxis = 0; n.midpoint = mid[0]; }
+    if (ey > ex && ey > ez) { n.longestAxis = 1; n.midpoint = mid[1]; }
+    if (ez > ex && ez > ey) { n.longestAxis = 2; n.midpoint = mid[2]; }
+}
+
+struct RefBuilder {
+    const crt_prim* prims;
+    const std::vector<Centroid>& cen;
+    RefTree& t;
+    std::vector<int> scratch;
+    RefBuilder(const crt_prim* p, const std::vector<Centroid>& c, RefTree& tt) : prims(p), cen(c), t(tt) {}
+
+    /* objects of node `ni` are t.order[first, first+count) */
+    int split(int ni, int first, int count, int depth) {
+        if (depth > t.depth) t.depth = depth;
+        if (count <= kMaxLeafPrims) {
+            RefNode& n = t.nodes[ni];
+            n.isleaf = true; n.first = first; n.count = count;
+            t.leafs.push_back(ni);
+            return 0;
+        }
+        if (depth > 256) return CRT_ERR_BUILD;
+        int li = (int)t.nodes.size();
+        t.nodes.emplace_back(); t.nodes.emplace_back();
+        int ri = li + 1;
+        RefNode zero; std::memset(&zero, 0, sizeof(zero));
+        zero.left = zero.right = -1; zero.parent = ni;
+        t.nodes[li] = zero; t.nodes[ri] = zero;
+        box_reset(t.nodes[li]); box_reset(t.nodes[ri]);
+        const int axis = (int)t.nodes[ni].longestAxis;
+        const float mid = t.nodes[ni].midpoint;
+        /* stable partition; centroid sums accumulate in object order (bvh.cu:85,130,151,196) */
+        float sumL[3] = {0, 0, 0}, sumR[3] = {0, 0, 0};
+        int nl = 0, nr = 0;
+        if ((int)scratch.size() < count) scratch.resize(count);
+        int* ord = &t.order[first];
+        for (int i = 0; i < count; i++) {
+            int o = ord[i];
+            if (cen[o].c[axis] <= mid) {
+                grow(t.nodes[li], prims[o]);
+                for (int a = 0; a < 3; a++) sumL[a] += cen[o].c[a];
+                ord[nl++] = o;
+            } else {
+                grow(t.nodes[ri], prims[o]);
+                for (int a = 0; a < 3; a++) sumR[a] += cen[o].c[a];
+                scratch[nr++] = o;
+            }
+        }
+        std::copy(scratch.begin(), scratch.begin() + nr, ord + nl);
+        float midL[3], midR[3];
+        for (int a = 0; a < 3; a++) { midL[a] = sumL[a] / (float)(size_t)nl; midR[a] = sumR[a] / (float)(size_t)nr; }
+        choose_axis(t.nodes[li], midL);
+        choose_axis(t.nodes[ri], midR);
+        t.nodes[ni].left = li; t.nodes[ni].right = ri;
+        int rc = split(li, first, nl, depth + 1);
+        if (rc) return rc;
+        return split(ri, first + nl, nr, depth + 1);
+    }
+};
+
+inline void prim_bounds(const crt_prim& o, float lo[3], float hi[3]) {
+    if (o.type == 0) {
+        for (int a = 0; a < 3; a++) { lo[a] = o.position[a] - o.radius; hi[a] = o.position[a] + o.radius; }
+    } else {
+        for (int a = 0; a < 3; a++) {
+            lo[a] = std::min(o.v1[a], std::min(o.v2[a], o.v3[a]));
+            hi[a] = std::max(o.v1[a], std::max(o.v2[a], o.v3[a]));
+        }
+    }
+}
+
+void node4_clear(Node4& n) {
+    for (int k = 0; k < 4; k++) {
+        n.lox[k] = n.loy[k] = n.loz[k] = kFmax;
+        n.hix[k] = n.hiy[k] = n.hiz[k] = -kFmax;
+        n.child[k] = kChildEmpty;
+    }
+    n.parent = kChildEmpty; n.parent_slot = 0; n.n_internal = 0; n.pad = 0;
+}
+
+}  // namespace
+
+int build_reference_tree(const crt_prim* prims, int n, RefTree& t) {
+    t.nodes.clear(); t.order.resize(n); t.leafs.clear(); t.depth = 0;
+    for (int i = 0; i < n; i++) t.order[i] = i;
+    std::vector<Centroid> cen(n);
+    for (int i = 0; i < n; i++) cen[i] = centroid_of(prims[i]);
+    /* newBuild, main.cu:33-136 */
+    RefNode root; std::memset(&root, 0, sizeof(root));
+    root.parent = -1; root.left = root.right = -1;
+    box_reset(root);
+    for (int i = 0; i < n; i++) grow(root, prims[i]);
+    float mid[3] = {(root.maxX + root.minX) / 2, (root.maxY + root.minY) / 2, (root.maxZ + root.minZ) / 2};
+    choose_axis(root, mid);
+    t.nodes.push_back(root);
+    t.nodes.reserve(n / 16 + 64);
+    RefBuilder b(prims, cen, t);
+    return b.split(0, 0, n, 0);
+}
+
+void refit_reference_tree(const crt_prim* prims, RefTree& t) {
+    /* bvh.cu:288-400: for every leaf walk to the root; boxes only grow.  min/max are exact and
+     * associative, so one bottom-up pass in reverse creation order gives the same boxes. */
+    for (int ni = (int)t.nodes.size() - 1; ni >= 0; ni--) {
+        RefNode& p = t.nodes[ni];
+        if (p.isleaf) {
+            for (int k = 0; k < p.count; k++) grow(p, prims[t.order[p.first + k]]);
+        } else {
+            const RefNode& l = t.nodes[p.left]; const RefNode& r = t.nodes[p.right];
+            const RefNode* cs[2] = {&l, &r};
+            for (const RefNode* c : cs) {
+                if (c->minX < p.minX) p.minX = c->minX;
+                if (c->maxX > p.maxX) p.maxX = c->maxX;
+                if (c->minY < p.minY) p.minY = c->minY;
+                if (c->maxY > p.maxY) p.maxY = c->maxY;
+                if (c->minZ < p.minZ) p.minZ = c->minZ;
+                if (c->maxZ > p.maxZ) p.maxZ = c->maxZ;
+            }
+        }
+    }
+}
+
+static void ranks_from(const RefTree& t, int n, std::vector<uint32_t>& rank) {
+    rank.assign(n, 0);
+    for (int i = 0; i < n; i++) rank[t.order[i]] = (uint32_t)i;
+}
+
+/* Reference topology in the packed format: every internal reference node becomes a Node4 using
+ * two child slots; reference leaves become leaf links (<=64 primitives); empty leaves become
+ * kChildEmpty but keep their (inverted) box so that dumps compare with the reference's. */
+int pack_reference(const crt_prim* prims, int n, const RefTree& t, HostBVH& out) {
+    (void)prims;
+    out.nodes.clear(); out.mode = CRT_BVH_REFERENCE; out.depth = t.depth + 1; out.leaves = (int)t.leafs.size();
+    out.slot_to_scene.resize(n);
+    for (int i = 0; i < n; i++) out.slot_to_scene[i] = (uint32_t)t.order[i];   /* slot == reference rank */
+    ranks_from(t, n, out.rank_of_scene);
+    const RefNode& r = t.nodes[0];
+    out.root_box[0] = r.minX; out.root_box[1] = r.maxX; out.root_box[2] = r.minY;
+    out.root_box[3] = r.maxY; out.root_box[4] = r.minZ; out.root_box[5] = r.maxZ;
+    auto set_box = [](Node4& nd, int k, const RefNode& c) {
+        nd.lox[k] = c.minX; nd.hix[k] = c.maxX; nd.loy[k] = c.minY; nd.hiy[k] = c.maxY; nd.loz[k] = c.minZ; nd.hiz[k] = c.maxZ;
+    };
+    auto leaf_link = [](const RefNode& c) { return c.count > 0 ? make_leaf((uint32_t)c.first, (uint32_t)c.count) : kChildEmpty; };
+    if (r.isleaf) {                     /* <= 64 objects: the whole scene is one leaf (Ray.cu:186-188) */
+        Node4 nd; node4_clear(nd);
+        set_box(nd, 0, r); nd.child[0] = leaf_link(r);
+        out.nodes.push_back(nd);
+        return 0;
+    }
+    /* map internal reference nodes to packed indices in creation order */
+    std::vector<int> packed(t.nodes.size(), -1);
+    int cnt = 0;
+    for (size_t i = 0; i < t.nodes.size(); i++) if (!t.nodes[i].isleaf) packed[i] = cnt++;
+    out.nodes.resize(cnt);
+    for (size_t i = 0; i < t.nodes.size(); i++) {
+        if (t.nodes[i].isleaf) continue;
+        Node4& nd = out.nodes[packed[i]]; node4_clear(nd);
+        const int ch[2] = {t.nodes[i].left, t.nodes[i].right};
+        for (int k = 0; k < 2; k++) {
+            const RefNode& c = t.nodes[ch[k]];
+            set_box(nd, k, c);
+            if (c.isleaf) nd.child[k] = leaf_link(c);
+            else { nd.child[k] = (uint32_t)packed[ch[k]]; nd.n_internal++; }
+        }
+    }
+    for (size_t i = 0; i < t.nodes.size(); i++) {
+        if (t.nodes[i].isleaf) continue;
+        const int ch[2] = {t.nodes[i].left, t.nodes[i].right};
+        for (int k = 0; k < 2; k++)
+            if (!t.nodes[ch[k]].isleaf) { Node4& c = out.nodes[packed[ch[k]]]; c.parent = (uint32_t)packed[i]; c.parent_slot = (uint32_t)k; }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Wide builder: binned SAH (16 bins, 3 axes) binary tree, then collapse to 4 children per node.
+ * ------------------------------------------------------------------------------------------ */
+namespace {
+
+struct AABB {
+    float lo[3], hi[3];
+    void reset() { for (int a = 0; a < 3; a++) { lo[a] = kFmax; hi[a] = -kFmax; } }
+    void add(const float l[3], const float h[3]) { for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], l[a]); hi[a] = std::max(hi[a], h[a]); } }
+    void add(const AABB& b) { add(b.lo, b.hi); }
+    void addp(const float p[3]) { for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); } }
+    float area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (dx < 0 || dy < 0 || dz < 0) return 0.f;
+        return 2.f * (dx * dy + dy * dz + dz * dx);
+    }
+};
+
+struct BNode { AABB box; int left, right; int first, count; };   /* leaf when left < 0 */
+
+struct PrimRef { AABB box; float c[3]; int idx; };
+
+constexpr int kBins = 16;
+constexpr int kWideLeaf = 4;
+
+struct WideBuilder {
+    std::vector<PrimRef>& refs;
+    std::vector<BNode> nodes;
+    explicit WideBuilder(std::vector<PrimRef>& r) : refs(r) {}
+
+    int build(int first, int count) {
+        int ni = (int)nodes.size();
+        nodes.emplace_back();
+        AABB box, cb; box.reset(); cb.reset();
+        for (int i = first; i < first + count; i++) { box.add(refs[i].box); cb.addp(refs[i].c); }
+        nodes[ni].box = box; nodes[ni].left = nodes[ni].right = -1; nodes[ni].first = first; nodes[ni].count = count;
+        if (count <= kWideLeaf) return ni;
+        int bestAxis = -1, bestSplit = -1; float bestCost = kFmax;
+        for (int a = 0; a < 3; a++) {
+            float ext = cb.hi[a] - cb.lo[a];
+            if (!(ext > 0.f)) continue;
+            AABB bb[kBins]; int bc[kBins];
+            for (int b = 0; b < kBins; b++) { bb[b].reset(); bc[b] = 0; }
+            float scale = (float)kBins / ext;
+            for (int i = first; i < first + count; i++) {
+                int b = (int)((refs[i].c[a] - cb.lo[a]) * scale);
+                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                bb[b].add(refs[i].box); bc[b]++;
+            }
+            float rightArea[kBins]; int rightCnt[kBins];
+            AABB acc; acc.reset(); int c = 0;
+            for (int b = kBins - 1; b > 0; b--) { acc.add(bb[b]); c += bc[b]; rightArea[b] = acc.area(); rightCnt[b] = c; }
+            acc.reset(); c = 0;
+            for (int b = 0; b < kBins - 1; b++) {
+                acc.add(bb[b]); c += bc[b];
+                if (c == 0 || rightCnt[b + 1] == 0) continue;
+                float cost = acc.area() * (float)c + rightArea[b + 1] * (float)rightCnt[b + 1];
+                if (cost < bestCost) { bestCost = cost; bestAxis = a; bestSplit = b; }
+            }
+        }
+        int mid;
+        if (bestAxis < 0) {
+            mid = first + count / 2;            /* all centroids coincide: split by count */
+        } else {
+            float ext = cb.hi[bestAxis] - cb.lo[bestAxis];
+            float scale = (float)kBins / ext; float lo = cb.lo[bestAxis]; int a = bestAxis, s = bestSplit;
+            auto it = std::partition(refs.begin() + first, refs.begin() + first + count, [&](const PrimRef& r) {
+                int b = (int)((r.c[a] - lo) * scale);
+                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                return b <= s;
+            });
+            mid = (int)(it - refs.begin());
+            if (mid == first || mid == first + count) mid = first + count / 2;
+        }
+        int l = build(first, mid - first);
+        int r = build(mid, first + count - mid);
+        nodes[ni].left = l; nodes[ni].right = r;
+        return ni;
+    }
+};
+
+}  // namespace
+
+int build_wide(const crt_prim* prims, int n, const RefTree* ref, HostBVH& out) {
+    out.nodes.clear(); out.mode = CRT_BVH_WIDE; out.depth = 0; out.leaves = 0;
+    out.slot_to_scene.clear(); out.slot_to_scene.reserve(n);
+    if (ref) ranks_from(*ref, n, out.rank_of_scene);
+    else { out.rank_of_scene.resize(n); for (int i = 0; i < n; i++) out.rank_of_scene[i] = (uint32_t)i; }
+
+    std::vector<PrimRef> refs(n);
+    for (int i = 0; i < n; i++) {
+        prim_bounds(prims[i], refs[i].box.lo, refs[i].box.hi);
+        for (int a = 0; a < 3; a++) refs[i].c[a] = 0.5f * (refs[i].box.lo[a] + refs[i].box.hi[a]);
+        refs[i].idx = i;
+    }
+    WideBuilder wb(refs);
+    wb.nodes.reserve((size_t)n);
+    if (n > 0) wb.build(0, n);
+
+    Node4 rootn; node4_clear(rootn);
+    out.nodes.push_back(rootn);
+    AABB rb; rb.reset();
+    if (n > 0) rb = wb.nodes[0].box;
+    out.root_box[0] = rb.lo[0]; out.root_box[1] = rb.hi[0]; out.root_box[2] = rb.lo[1];
+    out.root_box[3] = rb.hi[1]; out.root_box[4] = rb.lo[2]; out.root_box[5] = rb.hi[2];
+    if (n == 0) return 0;
+
+    /* collapse: (binary node, packed index, depth); slots are assigned in DFS leaf order */
+    struct Item { int b; int p; int depth; };
+    std::vector<Item> stack;
+    stack.push_back({0, 0, 1});
+    while (!stack.empty()) {
+        Item it = stack.back(); stack.pop_back();
+        if (it.depth > out.depth) out.depth = it.depth;
+        int kids[4]; int nk = 0;
+        const BNode& bn = wb.nodes[it.b];
+        if (bn.left < 0) kids[nk++] = it.b;
+        else { kids[nk++] = bn.left; kids[nk++] = bn.right; }
+        while (nk < 4) {
+            int best = -1; float bestA = -1.f;
+            for (int k = 0; k < nk; k++) {
+                const BNode& c = wb.nodes[kids[k]];
+                if (c.left < 0) continue;
+                float a = c.box.area();
+                if (a > bestA) { bestA = a; best = k; }
+            }
+            if (best < 0) break;
+            int c = kids[best];
+            kids[best] = wb.nodes[c].left;
+            kids[nk++] = wb.nodes[c].right;
+        }
+        /* children pushed in reverse so that child 0 is expanded first (DFS slot order) */
+        int childPacked[4];
+        for (int k = 0; k < nk; k++) {
+            const BNode& c = wb.nodes[kids[k]];
+            Node4& nd = out.nodes[it.p];
+            nd.lox[k] = c.box.lo[0]; nd.loy[k] = c.box.lo[1]; nd.loz[k] = c.box.lo[2];
+            nd.hix[k] = c.box.hi[0]; nd.hiy[k] = c.box.hi[1]; nd.hiz[k] = c.box.hi[2];
+            if (c.left < 0) { childPacked[k] = -1; }
+            else {
+                childPacked[k] = (int)out.nodes.size();
+                Node4 nn; node4_clear(nn); nn.parent = (uint32_t)it.p; nn.parent_slot = (uint32_t)k;
+                out.nodes.push_back(nn);
+                out.nodes[it.p].child[k] = (uint32_t)childPacked[k];
+                out.nodes[it.p].n_internal++;
+            }
+        }
+        for (int k = 0; k < nk; k++) {
+            const BNode& c = wb.nodes[kids[k]];
+            if (c.left < 0) {
+                uint32_t start = (uint32_t)out.slot_to_scene.size();
+                for (int i = c.first; i < c.first + c.count; i++) out.slot_to_scene.push_back((uint32_t)refs[i].idx);
+                out.nodes[it.p].child[k] = make_leaf(start, (uint32_t)c.count);
+                out.leaves++;
+            }
+        }
+        for (int k = nk - 1; k >= 0; k--)
+            if (childPacked[k] >= 0) stack.push_back({kids[k], childPacked[k], it.depth + 1});
+    }
+    return 0;
+}
+
+}  // namespace crt

@@ -1,0 +1,832 @@
+/* crt_api.cpp -- implementation of the C ABI in include/crt.h on top of the HIP kernels.
+ *
+ * Frame flow (replaces startRayTracing, Ray.cu:665-742), all on one HIP stream with queue sizes
+ * kept on the device -- no host synchronisation between kernels, where the reference calls
+ * cudaDeviceSynchronize after every launch and copies the Isect array to the host every bounce:
+ *
+ *   gen_primary -> [ trace(nearest) -> shade -> trace(shadow) -> resolve ] x bounces -> convert
+ *
+ * Paths whose reflection coefficient is zero (after any wall hit, Ray.cu:257,262) are not traced
+ * further; they contribute exactly zero in the reference, so the image is unchanged.
+ */
+#include "../../include/crt.h"
+#include "kernels.h"
+#include "bvh_build.h"
+#include "vec.h"
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include <map>
+#include <array>
+#include <chrono>
+#include <cstring>
+#include <cmath>
+#include <cstdio>
+
+using namespace crt;
+
+namespace {
+constexpr int kMaxBounces = 16;
+constexpr int kCtrStride = 64;
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+}
+
+struct crt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool counting = false, capture = false;
+
+    std::vector<crt_prim> prims;
+    std::vector<uint32_t> matid;
+    std::vector<Material> mats;
+    LightsParam lights{};
+    RefTree ref;
+    HostBVH bvh;
+    bool built = false, have_ref = false, imported = false;
+
+    /* packed scene */
+    void* d_blob = nullptr; size_t blob_bytes = 0; size_t blob_cap = 0;
+    BlobHeader hdr{};
+    crt_prim* d_prims = nullptr; uint32_t* d_matid = nullptr; size_t prim_cap = 0;
+    uint32_t* d_arrive = nullptr; size_t arrive_cap = 0;
+    float scene_abs = 0.f;
+
+    /* frame */
+    size_t cap = 0, npix_alloc = 0, nlights_alloc = 0;
+    float4 *rayO[2] = {nullptr, nullptr}, *rayD[2] = {nullptr, nullptr}, *coef[2] = {nullptr, nullptr};
+    uint32_t* pix[2] = {nullptr, nullptr};
+    int32_t* hitSlot = nullptr; float* hitT = nullptr;
+    float4 *rc = nullptr, *contrib = nullptr, *shO = nullptr, *shD = nullptr, *accum = nullptr, *sum = nullptr;
+    uint8_t* shflag = nullptr;
+    uint8_t* d_bgr = nullptr; size_t bgr_cap = 0;
+    int32_t* cap_ids = nullptr; float* cap_ts = nullptr; size_t cap_planes = 0; size_t cap_npix = 0;
+    uint32_t* d_tiles = nullptr; size_t tiles_cap = 0; std::vector<uint32_t> tiles; crt_params tiles_for{};
+    uint32_t* d_ctr = nullptr; size_t ctr_cap = 0; std::vector<uint32_t> h_ctr;
+    uint32_t* d_status = nullptr;
+    unsigned long long* d_testctr = nullptr;
+    uint32_t* d_ovf = nullptr; size_t ovf_cap = 0; int ovf_depth = 0;
+    int grid_blocks = 1024;
+    int last_w = 0, last_h = 0, last_bounces = 0;
+
+    struct Ev { hipEvent_t e; int kind; };
+    std::vector<hipEvent_t> evpool; size_t evused = 0;
+    std::vector<std::pair<int, int>> evlog;      /* (kind, event index) */
+    crt_stats stats{};
+};
+
+namespace {
+
+#define HIPCHECK(ctx, call)                                                                         \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                         \
+            return CRT_ERR_HIP;                                                                     \
+        }                                                                                           \
+    } while (0)
+
+int fail(crt_ctx* c, int code, const char* msg) { if (c) c->err = msg; return code; }
+
+template <class T>
+int ensure(crt_ctx* c, T*& p, size_t& cap, size_t need) {
+    if (need <= cap && p) return CRT_OK;
+    if (p) { HIPCHECK(c, hipFree(p)); p = nullptr; cap = 0; }
+    size_t want = need + need / 8 + 64;
+    HIPCHECK(c, hipMalloc((void**)&p, want * sizeof(T)));
+    cap = want;
+    return CRT_OK;
+}
+template <class T>
+int realloc_exact(crt_ctx* c, T*& p, size_t count) {
+    if (p) { HIPCHECK(c, hipFree(p)); p = nullptr; }
+    if (count) HIPCHECK(c, hipMalloc((void**)&p, count * sizeof(T)));
+    return CRT_OK;
+}
+
+SceneView view_of(const crt_ctx* c) {
+    SceneView v{};
+    const char* b = (const char*)c->d_blob;
+    v.nodes = (const Node4*)(b + c->hdr.off_nodes);
+    v.geom = (const Geom*)(b + c->hdr.off_geom);
+    v.shade = (const Shade*)(b + c->hdr.off_shade);
+    v.rank = (const uint32_t*)(b + c->hdr.off_rank);
+    v.sidx = (const uint32_t*)(b + c->hdr.off_sidx);
+    v.mats = (const Material*)(b + c->hdr.off_mats);
+    v.nprims = c->hdr.nprims; v.nnodes = c->hdr.nnodes;
+    return v;
+}
+
+void dedupe_materials(crt_ctx* c) {
+    std::map<std::array<uint32_t, 13>, uint32_t> seen;
+    c->mats.clear(); c->matid.resize(c->prims.size());
+    for (size_t i = 0; i < c->prims.size(); i++) {
+        const crt_prim& p = c->prims[i];
+        std::array<uint32_t, 13> key;
+        memcpy(&key[0], p.ambient, 12); memcpy(&key[3], p.diffuse, 12); memcpy(&key[6], p.specular, 12);
+        memcpy(&key[9], p.reflective, 12); memcpy(&key[12], &p.shininess, 4);
+        auto it = seen.find(key);
+        if (it == seen.end()) {
+            Material m{};
+            memcpy(m.ambient, p.ambient, 12); memcpy(m.diffuse, p.diffuse, 12); memcpy(m.specular, p.specular, 12);
+            memcpy(m.reflective, p.reflective, 12); m.shininess = p.shininess;
+            it = seen.emplace(key, (uint32_t)c->mats.size()).first;
+            c->mats.push_back(m);
+        }
+        c->matid[i] = it->second;
+    }
+}
+
+int upload_prims(crt_ctx* c) {
+    const size_t n = c->prims.size();
+    if (n > c->prim_cap || !c->d_prims) {
+        if (c->d_prims) HIPCHECK(c, hipFree(c->d_prims));
+        if (c->d_matid) HIPCHECK(c, hipFree(c->d_matid));
+        c->d_prims = nullptr; c->d_matid = nullptr;
+        HIPCHECK(c, hipMalloc((void**)&c->d_prims, (n + 1) * sizeof(crt_prim)));
+        HIPCHECK(c, hipMalloc((void**)&c->d_matid, (n + 1) * sizeof(uint32_t)));
+        c->prim_cap = n;
+    }
+    HIPCHECK(c, hipMemcpyAsync(c->d_prims, c->prims.data(), n * sizeof(crt_prim), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(c->d_matid, c->matid.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    return CRT_OK;
+}
+
+void layout_blob(BlobHeader& h) {
+    size_t off = align_up(sizeof(BlobHeader), 256);
+    h.off_nodes = off; off = align_up(off + (size_t)h.nnodes * sizeof(Node4), 256);
+    h.off_geom = off; off = align_up(off + (size_t)h.nprims * sizeof(Geom), 256);
+    h.off_shade = off; off = align_up(off + (size_t)h.nprims * sizeof(Shade), 256);
+    h.off_rank = off; off = align_up(off + (size_t)h.nprims * 4, 256);
+    h.off_sidx = off; off = align_up(off + (size_t)h.nprims * 4, 256);
+    h.off_slot_of = off; off = align_up(off + (size_t)h.nprims * 4, 256);
+    h.off_mats = off; off = align_up(off + (size_t)h.nmats * sizeof(Material), 256);
+    h.total_bytes = off;
+}
+
+int size_overflow(crt_ctx* c) {
+    /* worst-case stack need: 3 pushes per 4-wide level (+1), 1 per level for the 2-wide reference topology */
+    const int bound = (c->hdr.mode == CRT_BVH_WIDE ? 3 : 1) * (int)c->hdr.depth + 2;
+    c->ovf_depth = bound > kStackDepth ? bound - kStackDepth : 0;
+    const size_t need = (size_t)c->grid_blocks * kTraceBlock * (size_t)c->ovf_depth;
+    if (need > c->ovf_cap || !c->d_ovf) {
+        if (c->d_ovf) HIPCHECK(c, hipFree(c->d_ovf));
+        c->d_ovf = nullptr;
+        HIPCHECK(c, hipMalloc((void**)&c->d_ovf, (need + 64) * sizeof(uint32_t)));
+        c->ovf_cap = need;
+    }
+    return CRT_OK;
+}
+
+void scene_abs_from_box(crt_ctx* c) {
+    float m = 0.f;
+    for (int k = 0; k < 6; k++) { float a = fabsf(c->hdr.root_box[k]); if (a < 1e30f && a > m) m = a; }
+    c->scene_abs = m;
+}
+
+hipEvent_t next_event(crt_ctx* c) {
+    if (c->evused == c->evpool.size()) { hipEvent_t e; hipEventCreate(&e); c->evpool.push_back(e); }
+    return c->evpool[c->evused++];
+}
+enum { EV_START = 0, EV_GEN, EV_TRACE_N, EV_SHADE, EV_TRACE_S, EV_RESOLVE, EV_CONVERT };
+void mark(crt_ctx* c, int kind) {
+    hipEvent_t e = next_event(c);
+    hipEventRecord(e, c->stream);
+    c->evlog.emplace_back(kind, (int)c->evused - 1);
+}
+
+int ensure_tiles(crt_ctx* c, const crt_params* p) {
+    if (c->d_tiles && memcmp(&c->tiles_for, p, sizeof(crt_params)) == 0) return CRT_OK;
+    int nt = 0; int64_t np = 0;
+    int rc = crt_tiles_owned(p, &nt, &np, nullptr, 0);
+    if (rc) return fail(c, rc, "bad tile parameters");
+    c->tiles.resize(nt);
+    std::vector<int32_t> tmp(nt);
+    crt_tiles_owned(p, &nt, &np, tmp.data(), nt);
+    for (int i = 0; i < nt; i++) c->tiles[i] = (uint32_t)tmp[i];
+    rc = ensure(c, c->d_tiles, c->tiles_cap, (size_t)nt + 1);
+    if (rc) return rc;
+    HIPCHECK(c, hipMemcpyAsync(c->d_tiles, c->tiles.data(), nt * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    c->tiles_for = *p;
+    return CRT_OK;
+}
+
+int ensure_frame(crt_ctx* c, size_t cap, size_t npix, int bounces, int nlights, bool need_sum) {
+    if (cap > c->cap || !c->hitSlot) {
+        for (int k = 0; k < 2; k++) {
+            int r;
+            if ((r = realloc_exact(c, c->rayO[k], cap))) return r;
+            if ((r = realloc_exact(c, c->rayD[k], cap))) return r;
+            if ((r = realloc_exact(c, c->coef[k], cap))) return r;
+            if ((r = realloc_exact(c, c->pix[k], cap))) return r;
+        }
+        int r;
+        if ((r = realloc_exact(c, c->hitSlot, cap))) return r;
+        if ((r = realloc_exact(c, c->hitT, cap))) return r;
+        if ((r = realloc_exact(c, c->rc, cap))) return r;
+        c->cap = cap; c->nlights_alloc = 0;
+    }
+    const size_t nl = nlights > 0 ? (size_t)nlights : 1;
+    if (nl > c->nlights_alloc) {
+        int r;
+        if ((r = realloc_exact(c, c->contrib, c->cap * nl))) return r;
+        if ((r = realloc_exact(c, c->shflag, c->cap * nl))) return r;
+        if ((r = realloc_exact(c, c->shO, c->cap * nl))) return r;
+        if ((r = realloc_exact(c, c->shD, c->cap * nl))) return r;
+        c->nlights_alloc = nl;
+    }
+    if (npix > c->npix_alloc || !c->accum) {
+        int r;
+        if ((r = realloc_exact(c, c->accum, npix))) return r;
+        if (c->sum) { HIPCHECK(c, hipFree(c->sum)); c->sum = nullptr; }
+        c->npix_alloc = npix;
+    }
+    if (need_sum && !c->sum) { int r; if ((r = realloc_exact(c, c->sum, c->npix_alloc))) return r; }
+    if (c->capture && ((size_t)bounces > c->cap_planes || npix > c->cap_npix || !c->cap_ids)) {
+        int r;
+        if ((r = realloc_exact(c, c->cap_ids, (size_t)bounces * npix))) return r;
+        if ((r = realloc_exact(c, c->cap_ts, (size_t)bounces * npix))) return r;
+        c->cap_planes = bounces; c->cap_npix = npix;
+    }
+    return CRT_OK;
+}
+
+int check_status(crt_ctx* c) {
+    uint32_t st = 0;
+    HIPCHECK(c, hipMemcpy(&st, c->d_status, 4, hipMemcpyDeviceToHost));
+    if (st & 1u) {
+        uint32_t z = 0;
+        hipMemcpy(c->d_status, &z, 4, hipMemcpyHostToDevice);
+        return fail(c, CRT_ERR_STATE, "traversal stack overflow: tree deeper than the sized overflow area");
+    }
+    return CRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+crt_ctx* crt_create(int device, int* err) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { if (err) *err = CRT_ERR_HIP; return nullptr; }
+    if (device < 0 || device >= ndev) { if (err) *err = CRT_ERR_ARG; return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { if (err) *err = CRT_ERR_HIP; return nullptr; }
+    crt_ctx* c = new crt_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void**)&c->d_status, 4) != hipSuccess ||
+        hipMalloc((void**)&c->d_testctr, 3 * sizeof(unsigned long long)) != hipSuccess) {
+        if (err) *err = CRT_ERR_HIP;
+        delete c;
+        return nullptr;
+    }
+    hipMemset(c->d_status, 0, 4);
+    hipMemset(c->d_testctr, 0, 3 * sizeof(unsigned long long));
+    c->grid_blocks = trace_grid_blocks(device);
+    if (err) *err = CRT_OK;
+    return c;
+}
+
+void crt_destroy(crt_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    void* ptrs[] = {c->d_blob, c->d_prims, c->d_matid, c->d_arrive, c->rayO[0], c->rayO[1], c->rayD[0], c->rayD[1],
+                    c->coef[0], c->coef[1], c->pix[0], c->pix[1], c->hitSlot, c->hitT, c->rc, c->contrib, c->shO, c->shD,
+                    c->accum, c->sum, c->shflag, c->d_bgr, c->cap_ids, c->cap_ts, c->d_tiles, c->d_ctr, c->d_status,
+                    c->d_testctr, c->d_ovf};
+    for (void* p : ptrs) if (p) hipFree(p);
+    for (hipEvent_t e : c->evpool) hipEventDestroy(e);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* crt_last_error(crt_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+void crt_params_default(crt_params* p) {
+    memset(p, 0, sizeof *p);
+    p->width = 720; p->height = 360;        /* main.cu:141-142 */
+    p->bounces = 2;                          /* Ray.cu:27 */
+    p->spp = 1; p->tile_w = 32; p->tile_h = 32; p->rank = 0; p->nranks = 1; p->sort_rays = 0;
+}
+
+int crt_set_counting(crt_ctx* c, int on) { if (!c) return CRT_ERR_ARG; c->counting = on != 0; return CRT_OK; }
+int crt_set_capture(crt_ctx* c, int on) { if (!c) return CRT_ERR_ARG; c->capture = on != 0; return CRT_OK; }
+
+int crt_scene_set(crt_ctx* c, const crt_prim* prims, int n) {
+    if (!c || n < 0 || (n > 0 && !prims)) return fail(c, CRT_ERR_ARG, "crt_scene_set: bad arguments");
+    if (n > CRT_MAX_PRIMS) return fail(c, CRT_ERR_ARG, "crt_scene_set: too many primitives");
+    for (int i = 0; i < n; i++)
+        if (prims[i].type != 0 && prims[i].type != 1) return fail(c, CRT_ERR_ARG, "crt_scene_set: type must be 0 (sphere) or 1 (triangle)");
+    HIPCHECK(c, hipSetDevice(c->device));
+    c->prims.assign(prims, prims + n);
+    dedupe_materials(c);
+    c->built = false; c->have_ref = false; c->imported = false;
+    return upload_prims(c);
+}
+
+int crt_scene_update(crt_ctx* c, const crt_prim* prims, int n) {
+    if (!c || !prims) return fail(c, CRT_ERR_ARG, "crt_scene_update: bad arguments");
+    if (c->imported) return fail(c, CRT_ERR_STATE, "crt_scene_update: scene was imported as a blob; set it with crt_scene_set first");
+    if ((size_t)n != c->prims.size()) return fail(c, CRT_ERR_ARG, "crt_scene_update: count differs from crt_scene_set");
+    for (int i = 0; i < n; i++)
+        if (prims[i].type != c->prims[i].type) return fail(c, CRT_ERR_ARG, "crt_scene_update: primitive type changed");
+    HIPCHECK(c, hipSetDevice(c->device));
+    /* materials keep their ids: only geometry (and normals) move, main.cu:545-573 */
+    for (int i = 0; i < n; i++) {
+        crt_prim& d = c->prims[i]; const crt_prim& s = prims[i];
+        memcpy(d.position, s.position, 12); d.radius = s.radius;
+        memcpy(d.v1, s.v1, 12); memcpy(d.v2, s.v2, 12); memcpy(d.v3, s.v3, 12);
+        memcpy(d.v1Norm, s.v1Norm, 12); memcpy(d.v2Norm, s.v2Norm, 12); memcpy(d.v3Norm, s.v3Norm, 12);
+        memcpy(d.direction, s.direction, 12); d.speed = s.speed;
+    }
+    int rc = upload_prims(c);
+    if (rc) return rc;
+    if (c->built) {
+        char* b = (char*)c->d_blob;
+        launch_pack_prims(c->d_prims, c->d_matid, (const uint32_t*)(b + c->hdr.off_slot_of), (uint32_t)n,
+                          (Geom*)(b + c->hdr.off_geom), (Shade*)(b + c->hdr.off_shade), c->stream);
+        HIPCHECK(c, hipGetLastError());
+    }
+    return CRT_OK;
+}
+
+int crt_lights_set(crt_ctx* c, const crt_light* lights, int n) {
+    if (!c || n < 0 || n > CRT_MAX_LIGHTS || (n > 0 && !lights)) return fail(c, CRT_ERR_ARG, "crt_lights_set: 0..CRT_MAX_LIGHTS lights");
+    memset(&c->lights, 0, sizeof c->lights);
+    for (int i = 0; i < n; i++) c->lights.l[i] = lights[i];
+    c->lights.n = n;
+    return CRT_OK;
+}
+
+int crt_bvh_build(crt_ctx* c, int mode) {
+    if (!c) return CRT_ERR_ARG;
+    if (mode != CRT_BVH_WIDE && mode != CRT_BVH_REFERENCE) return fail(c, CRT_ERR_ARG, "crt_bvh_build: unknown mode");
+    if (c->imported) return fail(c, CRT_ERR_STATE, "crt_bvh_build: scene was imported as a blob");
+    HIPCHECK(c, hipSetDevice(c->device));
+    const int n = (int)c->prims.size();
+    auto t0 = std::chrono::steady_clock::now();
+    int rc = build_reference_tree(c->prims.data(), n, c->ref);
+    if (rc) return fail(c, rc, "BVH build: reference split does not terminate (more than 64 primitives share a centroid)");
+    c->have_ref = true;
+    if (mode == CRT_BVH_WIDE) rc = build_wide(c->prims.data(), n, &c->ref, c->bvh);
+    else rc = pack_reference(c->prims.data(), n, c->ref, c->bvh);
+    if (rc) return fail(c, rc, "BVH build failed");
+    auto t1 = std::chrono::steady_clock::now();
+    c->stats.ms_build_host = std::chrono::duration<double, std::milli>(t1 - t0).count();
+
+    BlobHeader h{};
+    h.magic = kBlobMagic; h.version = kBlobVersion;
+    h.nprims = (uint32_t)n; h.nnodes = (uint32_t)c->bvh.nodes.size(); h.nmats = (uint32_t)c->mats.size();
+    h.depth = (uint32_t)c->bvh.depth; h.mode = (uint32_t)mode;
+    memcpy(h.root_box, c->bvh.root_box, sizeof h.root_box);
+    layout_blob(h);
+    if (h.total_bytes > c->blob_cap || !c->d_blob) {
+        if (c->d_blob) HIPCHECK(c, hipFree(c->d_blob));
+        c->d_blob = nullptr;
+        HIPCHECK(c, hipMalloc(&c->d_blob, h.total_bytes));
+        c->blob_cap = h.total_bytes;
+    }
+    c->blob_bytes = h.total_bytes; c->hdr = h;
+    char* b = (char*)c->d_blob;
+    std::vector<uint32_t> rank_slot(n), slot_of(n);
+    for (int s = 0; s < n; s++) {
+        const uint32_t si = c->bvh.slot_to_scene[s];
+        rank_slot[s] = c->bvh.rank_of_scene[si];
+        slot_of[si] = (uint32_t)s;
+    }
+    HIPCHECK(c, hipMemcpyAsync(b, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(b + h.off_nodes, c->bvh.nodes.data(), (size_t)h.nnodes * sizeof(Node4), hipMemcpyHostToDevice, c->stream));
+    if (n) {
+        HIPCHECK(c, hipMemcpyAsync(b + h.off_rank, rank_slot.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(c, hipMemcpyAsync(b + h.off_sidx, c->bvh.slot_to_scene.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(c, hipMemcpyAsync(b + h.off_slot_of, slot_of.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    if (h.nmats) HIPCHECK(c, hipMemcpyAsync(b + h.off_mats, c->mats.data(), (size_t)h.nmats * sizeof(Material), hipMemcpyHostToDevice, c->stream));
+    launch_pack_prims(c->d_prims, c->d_matid, (const uint32_t*)(b + h.off_slot_of), (uint32_t)n, (Geom*)(b + h.off_geom),
+                      (Shade*)(b + h.off_shade), c->stream);
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipStreamSynchronize(c->stream));      /* host staging vectors go out of scope */
+    rc = ensure(c, c->d_arrive, c->arrive_cap, (size_t)h.nnodes + 1);
+    if (rc) return rc;
+    scene_abs_from_box(c);
+    rc = size_overflow(c);
+    if (rc) return rc;
+    c->built = true;
+    c->stats.nodes = (int)h.nnodes; c->stats.prims = n; c->stats.depth = (int)h.depth; c->stats.leaves = c->bvh.leaves;
+    c->stats.scene_bytes = h.total_bytes;
+    return CRT_OK;
+}
+
+int crt_bvh_refit(crt_ctx* c, int grow_only) {
+    if (!c) return CRT_ERR_ARG;
+    if (!c->built) return fail(c, CRT_ERR_STATE, "crt_bvh_refit: no BVH (call crt_bvh_build)");
+    HIPCHECK(c, hipSetDevice(c->device));
+    char* b = (char*)c->d_blob;
+    hipEvent_t e0 = next_event(c), e1 = next_event(c);
+    c->evused -= 2;
+    HIPCHECK(c, hipEventRecord(e0, c->stream));
+    launch_refit((Node4*)(b + c->hdr.off_nodes), c->hdr.nnodes, (const Geom*)(b + c->hdr.off_geom), c->d_arrive,
+                 (float*)(b + offsetof(BlobHeader, root_box)), grow_only ? 1 : 0, c->stream);
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipEventRecord(e1, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(c->hdr.root_box, b + offsetof(BlobHeader, root_box), sizeof c->hdr.root_box, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1); c->stats.ms_refit = ms;
+    scene_abs_from_box(c);
+    return CRT_OK;
+}
+
+int crt_bvh_free(crt_ctx* c) {
+    if (!c) return CRT_ERR_ARG;
+    HIPCHECK(c, hipSetDevice(c->device));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    if (c->d_blob) { HIPCHECK(c, hipFree(c->d_blob)); c->d_blob = nullptr; }
+    c->blob_cap = c->blob_bytes = 0; c->built = false; c->imported = false;
+    c->ref = RefTree(); c->bvh = HostBVH(); c->have_ref = false;
+    return CRT_OK;
+}
+
+int crt_bvh_reference_order(crt_ctx* c, int32_t* rank_out, int n) {
+    if (!c || !rank_out) return CRT_ERR_ARG;
+    if (!c->have_ref) return fail(c, CRT_ERR_STATE, "crt_bvh_reference_order: no BVH");
+    if ((size_t)n != c->prims.size()) return fail(c, CRT_ERR_ARG, "crt_bvh_reference_order: n differs from the scene size");
+    for (int i = 0; i < n; i++) rank_out[c->ref.order[i]] = i;
+    return CRT_OK;
+}
+
+int crt_bvh_dump(crt_ctx* c, int32_t* nnodes, float* root_box6, float* child_boxes, uint32_t* child_links, int cap_nodes) {
+    if (!c || !nnodes) return CRT_ERR_ARG;
+    if (!c->built) return fail(c, CRT_ERR_STATE, "crt_bvh_dump: no BVH");
+    HIPCHECK(c, hipSetDevice(c->device));
+    *nnodes = (int32_t)c->hdr.nnodes;
+    if (!child_boxes || !child_links) return CRT_OK;
+    if (cap_nodes < (int)c->hdr.nnodes) return fail(c, CRT_ERR_ARG, "crt_bvh_dump: buffer too small");
+    std::vector<Node4> nodes(c->hdr.nnodes);
+    const char* b = (const char*)c->d_blob;
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, hipMemcpy(nodes.data(), b + c->hdr.off_nodes, nodes.size() * sizeof(Node4), hipMemcpyDeviceToHost));
+    if (root_box6) HIPCHECK(c, hipMemcpy(root_box6, b + offsetof(BlobHeader, root_box), 24, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < nodes.size(); i++)
+        for (int k = 0; k < 4; k++) {
+            float* o = child_boxes + (i * 4 + k) * 6;
+            o[0] = nodes[i].lox[k]; o[1] = nodes[i].hix[k]; o[2] = nodes[i].loy[k];
+            o[3] = nodes[i].hiy[k]; o[4] = nodes[i].loz[k]; o[5] = nodes[i].hiz[k];
+            child_links[i * 4 + k] = nodes[i].child[k];
+        }
+    return CRT_OK;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+
+int crt_tile_owner(int t, int nranks) {
+    if (nranks <= 1) return 0;
+    /* skewed round-robin: every rank gets a spatially uniform lattice of tiles (static balance) */
+    return (int)(((long long)t + 3LL * (t / nranks)) % nranks);
+}
+
+int crt_tiles_owned(const crt_params* p, int32_t* ntiles, int64_t* npixels, int32_t* tile_ids, int cap) {
+    if (!p || p->width <= 0 || p->height <= 0 || p->tile_w <= 0 || p->tile_h <= 0 || (p->tile_w & 7) || (p->tile_h & 7) ||
+        p->nranks < 1 || p->rank < 0 || p->rank >= p->nranks)
+        return CRT_ERR_ARG;
+    const int tx = (p->width + p->tile_w - 1) / p->tile_w, ty = (p->height + p->tile_h - 1) / p->tile_h;
+    int n = 0; int64_t np = 0;
+    for (int t = 0; t < tx * ty; t++) {
+        if (crt_tile_owner(t, p->nranks) != p->rank) continue;
+        if (tile_ids && n < cap) tile_ids[n] = t;
+        const int x0 = (t % tx) * p->tile_w, y0 = (t / tx) * p->tile_h;
+        const int w = (x0 + p->tile_w <= p->width) ? p->tile_w : p->width - x0;
+        const int h = (y0 + p->tile_h <= p->height) ? p->tile_h : p->height - y0;
+        np += (int64_t)w * h;
+        n++;
+    }
+    if (ntiles) *ntiles = n;
+    if (npixels) *npixels = np;
+    return CRT_OK;
+}
+
+static int fill_frame_params(crt_ctx* c, const crt_camera* cam, const crt_params* p, FrameParams& fp) {
+    if (!cam || !p) return fail(c, CRT_ERR_ARG, "render: null camera or params");
+    if (p->bounces < 1 || p->bounces > kMaxBounces) return fail(c, CRT_ERR_ARG, "render: bounces must be 1..16");
+    int sn = 1;
+    if (p->spp > 1) { sn = (int)lround(sqrt((double)p->spp)); if (sn * sn != p->spp || sn > 8) return fail(c, CRT_ERR_ARG, "render: spp must be a perfect square <= 64"); }
+    if ((int64_t)p->width * p->height > (1LL << 31) - 1) return fail(c, CRT_ERR_ARG, "render: frame too large");
+    /* Ray.cu:684-689 */
+    const float width = (float)p->width, height = (float)p->height;
+    const vec3 cameraPosition(cam->position), cameraDirection(cam->target);
+    const vec3 n = normalize(cameraPosition - cameraDirection);
+    const vec3 u = normalize(cross(vec3(0, 1, 0), n));
+    const vec3 v = cross(n, u);
+    const float fov = 45 / (180.0 / 3.14159265359);
+    const float d = (height / tanf(fov / 2)) / 2;
+    const vec3 L = (cameraPosition - n * d) - u * (width / 2) - v * (height / 2);
+    memset(&fp, 0, sizeof fp);
+    L.store(fp.L); u.store(fp.u); v.store(fp.v); cameraPosition.store(fp.cam);
+    fp.width = p->width; fp.height = p->height; fp.tile_w = p->tile_w; fp.tile_h = p->tile_h;
+    fp.tiles_x = (p->width + p->tile_w - 1) / p->tile_w;
+    fp.spp_n = sn; fp.bounces = p->bounces; fp.capture = c->capture ? 1 : 0;
+    return CRT_OK;
+}
+
+int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, void* dev_bgr) {
+    if (!c) return CRT_ERR_ARG;
+    if (!c->built) return fail(c, CRT_ERR_STATE, "render: no BVH (call crt_scene_set + crt_bvh_build, or import a blob)");
+    HIPCHECK(c, hipSetDevice(c->device));
+    FrameParams fp;
+    int rc = fill_frame_params(c, cam, p, fp);
+    if (rc) return rc;
+    rc = ensure_tiles(c, p);
+    if (rc) return rc;
+    fp.ntiles_owned = (int)c->tiles.size();
+    const size_t cap = (size_t)fp.ntiles_owned * p->tile_w * p->tile_h;
+    const size_t npix = (size_t)p->width * p->height;
+    const int spp = fp.spp_n * fp.spp_n;
+    rc = ensure_frame(c, cap > 0 ? cap : 64, npix, p->bounces, c->lights.n, spp > 1);
+    if (rc) return rc;
+    if (!dev_bgr) {
+        rc = ensure(c, c->d_bgr, c->bgr_cap, npix * 3);
+        if (rc) return rc;
+        dev_bgr = c->d_bgr;
+    }
+    rc = ensure(c, c->d_ctr, c->ctr_cap, (size_t)spp * kCtrStride);
+    if (rc) return rc;
+    c->h_ctr.assign((size_t)spp * kCtrStride, 0);
+    HIPCHECK(c, hipMemsetAsync(c->d_ctr, 0, (size_t)spp * kCtrStride * 4, c->stream));
+    if (c->counting) HIPCHECK(c, hipMemsetAsync(c->d_testctr, 0, 3 * sizeof(unsigned long long), c->stream));
+    if (c->capture) {
+        HIPCHECK(c, hipMemsetD32Async((hipDeviceptr_t)c->cap_ids, -9, (size_t)p->bounces * npix, c->stream));
+        HIPCHECK(c, hipMemsetD32Async((hipDeviceptr_t)c->cap_ts, 0, (size_t)p->bounces * npix, c->stream));
+    }
+    c->evused = 0; c->evlog.clear();
+    const SceneView sv = view_of(c);
+    mark(c, EV_START);
+    for (int s = 0; s < spp; s++) {
+        uint32_t* ctr = c->d_ctr + (size_t)s * kCtrStride;
+        fp.sample = s;
+        int cur = 0;
+        FrameBuffers fb{};
+        fb.hitSlot = c->hitSlot; fb.hitT = c->hitT; fb.rc = c->rc; fb.contrib = c->contrib; fb.shflag = c->shflag;
+        fb.shO = c->shO; fb.shD = c->shD; fb.accum = c->accum; fb.cap_ids = c->cap_ids; fb.cap_ts = c->cap_ts;
+        fb.cap = (uint32_t)c->cap; fb.cap_stride = (uint32_t)npix; fb.tile_ids = c->d_tiles;
+        auto bind = [&](int k) {
+            fb.rayO = c->rayO[k]; fb.rayD = c->rayD[k]; fb.coef = c->coef[k]; fb.pix = c->pix[k];
+            fb.nrayO = c->rayO[k ^ 1]; fb.nrayD = c->rayD[k ^ 1]; fb.ncoef = c->coef[k ^ 1]; fb.npix = c->pix[k ^ 1];
+        };
+        bind(cur);
+        launch_gen_primary(fp, fb, ctr + 0, c->stream);
+        mark(c, EV_GEN);
+        for (int b = 0; b < p->bounces; b++) {
+            fp.bounce = b;
+            bind(cur);
+            TraceArgs ta{};
+            ta.sv = sv; ta.rayO = fb.rayO; ta.rayD = fb.rayD; ta.count = ctr + b; ta.next = ctr + 32 + b;
+            ta.hitSlot = c->hitSlot; ta.hitT = c->hitT; ta.shflag = nullptr; ta.scene_abs = c->scene_abs;
+            ta.ovf = c->d_ovf; ta.ovf_depth = c->ovf_depth; ta.counters = c->d_testctr; ta.status = c->d_status;
+            launch_trace(ta, c->lights, TRACE_NEAREST, c->counting, c->grid_blocks, c->stream);
+            mark(c, EV_TRACE_N);
+            launch_shade(fp, fb, sv, c->lights, ctr + b, ctr + b + 1, ctr + 16 + b, c->stream);
+            mark(c, EV_SHADE);
+            if (c->lights.n > 0) {
+                TraceArgs ts = ta;
+                ts.rayO = c->shO; ts.rayD = c->shD; ts.count = ctr + 16 + b; ts.next = ctr + 48 + b;
+                ts.hitSlot = nullptr; ts.hitT = nullptr; ts.shflag = c->shflag;
+                launch_trace(ts, c->lights, TRACE_SHADOW, c->counting, c->grid_blocks, c->stream);
+                mark(c, EV_TRACE_S);
+            }
+            launch_resolve(fb, c->lights, ctr + b, c->stream);
+            mark(c, EV_RESOLVE);
+            cur ^= 1;
+        }
+        if (spp > 1) launch_spp_accumulate(fp, fb, c->sum, c->stream);
+    }
+    {
+        FrameBuffers fb{};
+        fb.accum = c->accum; fb.tile_ids = c->d_tiles;
+        launch_convert(fp, fb, spp > 1 ? c->sum : nullptr, (uint8_t*)dev_bgr, c->stream);
+        mark(c, EV_CONVERT);
+    }
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipMemcpyAsync(c->h_ctr.data(), c->d_ctr, (size_t)spp * kCtrStride * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    rc = check_status(c);
+    if (rc) return rc;
+
+    crt_stats& st = c->stats;
+    st.rays_primary = st.rays_shadow = st.rays_reflect = 0;
+    for (int s = 0; s < spp; s++) {
+        const uint32_t* h = &c->h_ctr[(size_t)s * kCtrStride];
+        st.rays_primary += h[0];
+        for (int b = 1; b < p->bounces; b++) st.rays_reflect += h[b];
+        for (int b = 0; b < p->bounces; b++) st.rays_shadow += h[16 + b];
+    }
+    st.ms_trace = st.ms_shade = st.ms_other = st.ms_trace_nearest = 0; st.launches_trace_nearest = 0;
+    for (size_t i = 1; i < c->evlog.size(); i++) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, c->evpool[c->evlog[i - 1].second], c->evpool[c->evlog[i].second]);
+        switch (c->evlog[i].first) {
+            case EV_TRACE_N: st.ms_trace += ms; st.ms_trace_nearest += ms; st.launches_trace_nearest++; break;
+            case EV_TRACE_S: st.ms_trace += ms; break;
+            case EV_SHADE: case EV_RESOLVE: st.ms_shade += ms; break;
+            default: st.ms_other += ms;
+        }
+    }
+    float tot = 0;
+    hipEventElapsedTime(&tot, c->evpool[c->evlog.front().second], c->evpool[c->evlog.back().second]);
+    st.ms_total = tot;
+    if (c->counting) {
+        unsigned long long t[3];
+        HIPCHECK(c, hipMemcpy(t, c->d_testctr, sizeof t, hipMemcpyDeviceToHost));
+        st.box_tests = t[0]; st.tri_tests = t[1]; st.sph_tests = t[2];
+    }
+    c->last_w = p->width; c->last_h = p->height; c->last_bounces = p->bounces;
+    return CRT_OK;
+}
+
+int crt_render(crt_ctx* c, const crt_camera* cam, const crt_params* p, unsigned char* bgr_out_host) {
+    if (!c || !bgr_out_host) return fail(c, CRT_ERR_ARG, "crt_render: null output buffer");
+    int rc = crt_render_device(c, cam, p, nullptr);
+    if (rc) return rc;
+    HIPCHECK(c, hipMemcpy(bgr_out_host, c->d_bgr, (size_t)p->width * p->height * 3, hipMemcpyDeviceToHost));
+    return CRT_OK;
+}
+
+int crt_get_capture(crt_ctx* c, int bounce, int32_t* ids, float* ts, int npixels) {
+    if (!c || !ids || !ts) return CRT_ERR_ARG;
+    if (!c->capture || !c->cap_ids) return fail(c, CRT_ERR_STATE, "crt_get_capture: capture was not enabled before the render");
+    if (bounce < 0 || bounce >= c->last_bounces || npixels != c->last_w * c->last_h) return fail(c, CRT_ERR_ARG, "crt_get_capture: bad bounce or size");
+    HIPCHECK(c, hipSetDevice(c->device));
+    HIPCHECK(c, hipMemcpy(ids, c->cap_ids + (size_t)bounce * npixels, (size_t)npixels * 4, hipMemcpyDeviceToHost));
+    HIPCHECK(c, hipMemcpy(ts, c->cap_ts + (size_t)bounce * npixels, (size_t)npixels * 4, hipMemcpyDeviceToHost));
+    return CRT_OK;
+}
+
+int crt_get_color(crt_ctx* c, float* rgb, int npixels) {
+    if (!c || !rgb) return CRT_ERR_ARG;
+    if (!c->accum || npixels != c->last_w * c->last_h) return fail(c, CRT_ERR_ARG, "crt_get_color: no frame of that size");
+    HIPCHECK(c, hipSetDevice(c->device));
+    std::vector<float4> tmp(npixels);
+    HIPCHECK(c, hipMemcpy(tmp.data(), c->accum, (size_t)npixels * sizeof(float4), hipMemcpyDeviceToHost));
+    for (int i = 0; i < npixels; i++) { rgb[3 * i] = tmp[i].x; rgb[3 * i + 1] = tmp[i].y; rgb[3 * i + 2] = tmp[i].z; }
+    return CRT_OK;
+}
+
+static int trace_hook(crt_ctx* c, const float* org_dir, int n, int32_t* prim_out, float* t_out, uint8_t* shadow_out) {
+    if (!c || !org_dir || n < 0) return fail(c, CRT_ERR_ARG, "crt_trace: bad arguments");
+    if (!c->built) return fail(c, CRT_ERR_STATE, "crt_trace: no BVH");
+    if (n == 0) return CRT_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    float* d_od = nullptr; float4 *d_o = nullptr, *d_d = nullptr; int32_t *d_slot = nullptr, *d_id = nullptr; float* d_t = nullptr;
+    uint8_t* d_flag = nullptr; uint32_t* d_cnt = nullptr;
+    int rc = CRT_OK;
+#define TH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { c->err = std::string(#call) + ": " + hipGetErrorString(e_); rc = CRT_ERR_HIP; goto done; } } while (0)
+    TH(hipMalloc((void**)&d_od, (size_t)n * 24)); TH(hipMalloc((void**)&d_o, (size_t)n * 16)); TH(hipMalloc((void**)&d_d, (size_t)n * 16));
+    TH(hipMalloc((void**)&d_slot, (size_t)n * 4)); TH(hipMalloc((void**)&d_id, (size_t)n * 4)); TH(hipMalloc((void**)&d_t, (size_t)n * 4));
+    TH(hipMalloc((void**)&d_flag, (size_t)n)); TH(hipMalloc((void**)&d_cnt, 8));
+    {
+        uint32_t cnt[2] = {(uint32_t)n, 0};
+        TH(hipMemcpyAsync(d_od, org_dir, (size_t)n * 24, hipMemcpyHostToDevice, c->stream));
+        TH(hipMemcpyAsync(d_cnt, cnt, 8, hipMemcpyHostToDevice, c->stream));
+        TH(hipMemsetAsync(d_flag, 0, (size_t)n, c->stream));
+        launch_pack_rays(d_od, (uint32_t)n, d_o, d_d, c->stream);
+        TraceArgs ta{};
+        ta.sv = view_of(c); ta.rayO = d_o; ta.rayD = d_d; ta.count = d_cnt; ta.next = d_cnt + 1;
+        ta.hitSlot = d_slot; ta.hitT = d_t; ta.shflag = d_flag; ta.scene_abs = c->scene_abs;
+        ta.ovf = c->d_ovf; ta.ovf_depth = c->ovf_depth; ta.counters = c->d_testctr; ta.status = c->d_status;
+        if (c->counting) TH(hipMemsetAsync(c->d_testctr, 0, 3 * sizeof(unsigned long long), c->stream));
+        LightsParam dummy{}; dummy.n = 1;          /* light 0 directional: the Ray.cu:650-656 predicate */
+        launch_trace(ta, dummy, shadow_out ? TRACE_SHADOW : TRACE_NEAREST, c->counting, c->grid_blocks, c->stream);
+        TH(hipGetLastError());
+        if (shadow_out) TH(hipMemcpyAsync(shadow_out, d_flag, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        else {
+            launch_slots_to_scene(d_slot, ta.sv.sidx, d_id, (uint32_t)n, c->stream);
+            TH(hipMemcpyAsync(prim_out, d_id, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+            TH(hipMemcpyAsync(t_out, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        }
+        TH(hipStreamSynchronize(c->stream));
+        if (c->counting) {
+            unsigned long long t[3];
+            TH(hipMemcpy(t, c->d_testctr, sizeof t, hipMemcpyDeviceToHost));
+            c->stats.box_tests = t[0]; c->stats.tri_tests = t[1]; c->stats.sph_tests = t[2];
+        }
+    }
+done:
+#undef TH
+    hipFree(d_od); hipFree(d_o); hipFree(d_d); hipFree(d_slot); hipFree(d_id); hipFree(d_t); hipFree(d_flag); hipFree(d_cnt);
+    if (rc) return rc;
+    return check_status(c);
+}
+
+int crt_trace(crt_ctx* c, const float* org_dir, int n, int32_t* prim_out, float* t_out) {
+    if (!prim_out || !t_out) return fail(c, CRT_ERR_ARG, "crt_trace: null outputs");
+    return trace_hook(c, org_dir, n, prim_out, t_out, nullptr);
+}
+int crt_trace_shadow(crt_ctx* c, const float* org_dir, int n, uint8_t* shadowed_out) {
+    if (!shadowed_out) return fail(c, CRT_ERR_ARG, "crt_trace_shadow: null output");
+    return trace_hook(c, org_dir, n, nullptr, nullptr, shadowed_out);
+}
+
+/* ---------------------------------------------------------------------------------------- */
+
+int crt_blob_size(crt_ctx* c, size_t* bytes) {
+    if (!c || !bytes) return CRT_ERR_ARG;
+    if (!c->built) return fail(c, CRT_ERR_STATE, "crt_blob_size: no BVH");
+    *bytes = c->blob_bytes;
+    return CRT_OK;
+}
+int crt_blob_device_ptr(crt_ctx* c, void** p) {
+    if (!c || !p) return CRT_ERR_ARG;
+    if (!c->built) return fail(c, CRT_ERR_STATE, "crt_blob_device_ptr: no BVH");
+    HIPCHECK(c, hipSetDevice(c->device));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    *p = c->d_blob;
+    return CRT_OK;
+}
+int crt_blob_import_device(crt_ctx* c, const void* dev_ptr, size_t bytes) {
+    if (!c || !dev_ptr || bytes < sizeof(BlobHeader)) return fail(c, CRT_ERR_ARG, "crt_blob_import_device: bad arguments");
+    HIPCHECK(c, hipSetDevice(c->device));
+    BlobHeader h;
+    HIPCHECK(c, hipMemcpy(&h, dev_ptr, sizeof h, hipMemcpyDeviceToHost));
+    if (h.magic != kBlobMagic || h.version != kBlobVersion || h.total_bytes != bytes) return fail(c, CRT_ERR_ARG, "crt_blob_import_device: not a scene blob of this version/size");
+    BlobHeader chk = h; layout_blob(chk);
+    if (chk.total_bytes != h.total_bytes || chk.off_mats != h.off_mats) return fail(c, CRT_ERR_ARG, "crt_blob_import_device: inconsistent header");
+    if (dev_ptr != c->d_blob) {
+        if (bytes > c->blob_cap || !c->d_blob) {
+            if (c->d_blob) HIPCHECK(c, hipFree(c->d_blob));
+            c->d_blob = nullptr;
+            HIPCHECK(c, hipMalloc(&c->d_blob, bytes));
+            c->blob_cap = bytes;
+        }
+        HIPCHECK(c, hipMemcpy(c->d_blob, dev_ptr, bytes, hipMemcpyDeviceToDevice));
+    }
+    c->blob_bytes = bytes; c->hdr = h; c->built = true; c->imported = (dev_ptr != c->d_blob) || c->prims.empty();
+    int rc = ensure(c, c->d_arrive, c->arrive_cap, (size_t)h.nnodes + 1);
+    if (rc) return rc;
+    scene_abs_from_box(c);
+    c->stats.nodes = (int)h.nnodes; c->stats.prims = (int)h.nprims; c->stats.depth = (int)h.depth; c->stats.scene_bytes = bytes;
+    return size_overflow(c);
+}
+
+static int tiles_copy(crt_ctx* c, const crt_params* p, int src_rank, const void* src, void* dst, int to_packed) {
+    if (!c || !p || !src || !dst) return fail(c, CRT_ERR_ARG, "tiles pack/unpack: null argument");
+    HIPCHECK(c, hipSetDevice(c->device));
+    crt_params q = *p; q.rank = src_rank;
+    int nt = 0; int64_t np = 0;
+    int rc = crt_tiles_owned(&q, &nt, &np, nullptr, 0);
+    if (rc) return fail(c, rc, "tiles pack/unpack: bad params");
+    std::vector<int32_t> ids(nt);
+    crt_tiles_owned(&q, &nt, &np, ids.data(), nt);
+    uint32_t* d_ids = nullptr;
+    HIPCHECK(c, hipMalloc((void**)&d_ids, (size_t)(nt + 1) * 4));
+    hipError_t e = hipMemcpyAsync(d_ids, ids.data(), (size_t)nt * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        FrameParams fp{};
+        fp.width = p->width; fp.height = p->height; fp.tile_w = p->tile_w; fp.tile_h = p->tile_h;
+        fp.tiles_x = (p->width + p->tile_w - 1) / p->tile_w; fp.ntiles_owned = nt;
+        launch_tiles_copy(fp, d_ids, nt, (const uint8_t*)src, (uint8_t*)dst, to_packed, c->stream);
+        e = hipStreamSynchronize(c->stream);
+    }
+    hipFree(d_ids);
+    if (e != hipSuccess) { c->err = std::string("tiles copy: ") + hipGetErrorString(e); return CRT_ERR_HIP; }
+    return CRT_OK;
+}
+int crt_tiles_pack(crt_ctx* c, const crt_params* p, const void* dev_bgr, void* dev_packed) {
+    return tiles_copy(c, p, p ? p->rank : 0, dev_bgr ? dev_bgr : (c ? c->d_bgr : nullptr), dev_packed, 1);
+}
+int crt_tiles_unpack(crt_ctx* c, const crt_params* p, int src_rank, const void* dev_packed, void* dev_bgr) {
+    return tiles_copy(c, p, src_rank, dev_packed, dev_bgr, 0);
+}
+
+int crt_get_stats(crt_ctx* c, crt_stats* out) { if (!c || !out) return CRT_ERR_ARG; *out = c->stats; return CRT_OK; }
+int crt_sync(crt_ctx* c) { if (!c) return CRT_ERR_ARG; HIPCHECK(c, hipSetDevice(c->device)); HIPCHECK(c, hipStreamSynchronize(c->stream)); return CRT_OK; }
+
+int crt_host_bvh(const crt_prim* prims, int n, int mode, int32_t* nnodes, int32_t* depth, float* root_box6,
+                 float* child_boxes, uint32_t* child_links, uint32_t* parents, uint32_t* slot_to_scene,
+                 uint32_t* rank_of_scene, int cap_nodes) {
+    if (n < 0 || (n > 0 && !prims) || !nnodes) return CRT_ERR_ARG;
+    if (mode != CRT_BVH_WIDE && mode != CRT_BVH_REFERENCE) return CRT_ERR_ARG;
+    RefTree ref; HostBVH bvh;
+    int rc = build_reference_tree(prims, n, ref);
+    if (rc) return rc;
+    rc = mode == CRT_BVH_WIDE ? build_wide(prims, n, &ref, bvh) : pack_reference(prims, n, ref, bvh);
+    if (rc) return rc;
+    *nnodes = (int32_t)bvh.nodes.size();
+    if (depth) *depth = bvh.depth;
+    if (root_box6) memcpy(root_box6, bvh.root_box, 24);
+    if (!child_boxes || !child_links) return CRT_OK;
+    if (cap_nodes < *nnodes) return CRT_ERR_ARG;
+    for (size_t i = 0; i < bvh.nodes.size(); i++) {
+        const Node4& nd = bvh.nodes[i];
+        for (int k = 0; k < 4; k++) {
+            float* o = child_boxes + (i * 4 + k) * 6;
+            o[0] = nd.lox[k]; o[1] = nd.hix[k]; o[2] = nd.loy[k]; o[3] = nd.hiy[k]; o[4] = nd.loz[k]; o[5] = nd.hiz[k];
+            child_links[i * 4 + k] = nd.child[k];
+        }
+        if (parents) { parents[2 * i] = nd.parent; parents[2 * i + 1] = nd.parent_slot; }
+    }
+    if (slot_to_scene) memcpy(slot_to_scene, bvh.slot_to_scene.data(), (size_t)n * 4);
+    if (rank_of_scene) memcpy(rank_of_scene, bvh.rank_of_scene.data(), (size_t)n * 4);
+    return CRT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,80 @@
+/* kernels.h -- launch interface between the C-ABI host layer (crt_api.cpp) and the HIP kernels
+ * (kernels.hip).  Everything here is plain data; no HIP types leak into crt.h. */
+#ifndef CRT_KERNELS_H
+#define CRT_KERNELS_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "layout.h"
+#include "../../include/crt.h"
+
+namespace crt {
+
+constexpr int kTraceBlock = 256;       /* 4 waves of 64 */
+constexpr int kStackDepth = 32;        /* per-lane entries in LDS: stack[depth][lane], conflict-free per wave */
+constexpr int kRefillMinIdle = 16;     /* a wave refills from the ray queue when >= this many lanes are idle */
+
+/* Camera basis of Ray.cu:684-689 plus the tile map of this rank. */
+struct FrameParams {
+    float L[3], u[3], v[3], cam[3];
+    int32_t width, height;
+    int32_t tile_w, tile_h, tiles_x;
+    int32_t ntiles_owned;
+    int32_t spp_n, sample;            /* spp = spp_n^2; sample in [0, spp) */
+    int32_t bounce, bounces;
+    int32_t capture;
+};
+
+struct LightsParam {
+    crt_light l[CRT_MAX_LIGHTS];
+    int32_t n;
+};
+
+/* Per-frame device buffers.  Queue entry i of the current bounce owns rayO/rayD/coef/pix[i];
+ * shading writes rc/contrib/shflag at [j*cap + i] for light j. */
+struct FrameBuffers {
+    float4* rayO; float4* rayD; float4* coef; uint32_t* pix;           /* current queue */
+    float4* nrayO; float4* nrayD; float4* ncoef; uint32_t* npix;       /* next-bounce queue */
+    int32_t* hitSlot; float* hitT;
+    float4* rc; float4* contrib; uint8_t* shflag;
+    float4* shO; float4* shD;                                          /* shadow-ray queue: .w = target / light */
+    float4* accum;                                                     /* per pixel float colour (isect.color) */
+    int32_t* cap_ids; float* cap_ts;                                   /* capture planes [bounce][pixel] or null */
+    uint32_t cap;                                                      /* queue capacity: stride of the per-light planes */
+    uint32_t cap_stride;                                               /* pixels per capture plane */
+    const uint32_t* tile_ids;
+};
+
+enum TraceMode { TRACE_NEAREST = 0, TRACE_SHADOW = 1 };
+
+struct TraceArgs {
+    SceneView sv;
+    const float4* rayO; const float4* rayD;
+    const uint32_t* count;       /* number of rays (device) */
+    uint32_t* next;              /* fetch counter (device, zeroed) */
+    int32_t* hitSlot; float* hitT;           /* NEAREST outputs */
+    uint8_t* shflag;                         /* SHADOW output, indexed by the target in rayO.w */
+    float scene_abs;             /* max |coordinate| of the root box: scales the slab-test pad */
+    uint32_t* ovf; int32_t ovf_depth;        /* per-thread stack overflow area in HBM */
+    unsigned long long* counters;            /* [0]=box [1]=tri [2]=sph tests, when counting */
+    uint32_t* status;            /* device error word: bit0 = stack overflow beyond ovf */
+};
+
+int trace_grid_blocks(int device);
+void launch_trace(const TraceArgs& a, const LightsParam& lights, int mode, bool counting, int blocks, hipStream_t s);
+void launch_gen_primary(const FrameParams& fp, const FrameBuffers& fb, uint32_t* count, hipStream_t s);
+void launch_shade(const FrameParams& fp, const FrameBuffers& fb, const SceneView& sv, const LightsParam& lights,
+                  const uint32_t* count, uint32_t* next_count, uint32_t* shadow_count, hipStream_t s);
+void launch_resolve(const FrameBuffers& fb, const LightsParam& lights, const uint32_t* count, hipStream_t s);
+void launch_convert(const FrameParams& fp, const FrameBuffers& fb, const float4* sum_or_null, uint8_t* bgr, hipStream_t s);
+void launch_spp_accumulate(const FrameParams& fp, const FrameBuffers& fb, float4* sum, hipStream_t s);
+void launch_pack_prims(const crt_prim* d_prims, const uint32_t* d_matid, const uint32_t* slot_of, uint32_t n,
+                       Geom* geom, Shade* shade, hipStream_t s);
+void launch_refit(Node4* nodes, uint32_t nnodes, const Geom* geom, uint32_t* arrive, float* root_box, int grow_only,
+                  hipStream_t s);
+void launch_slots_to_scene(const int32_t* slots, const uint32_t* sidx, int32_t* out, uint32_t n, hipStream_t s);
+void launch_pack_rays(const float* org_dir, uint32_t n, float4* rayO, float4* rayD, hipStream_t s);
+void launch_tiles_copy(const FrameParams& fp, const uint32_t* tile_ids, int ntiles, const uint8_t* src, uint8_t* dst,
+                       int to_packed, hipStream_t s);
+
+}  // namespace crt
+#endif

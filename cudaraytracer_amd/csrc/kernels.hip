@@ -1,0 +1,750 @@
+/* kernels.hip -- hand-written CDNA4 (gfx950) kernels of the render path.
+ *
+ * Built with -ffp-contract=off: the reference's hit/no-hit predicates are threshold tests on float
+ * expressions (Ray.cu:114,122,126,148,151,158) and must be evaluated with the same roundings as a
+ * non-contracting build; IEEE divide/sqrt are hipcc's default.  The only fused operations are the
+ * explicit fmaf() of the box test, which only has to be conservative.
+ *
+ * Design (wave64, no MFMA -- nothing here is a dense contraction):
+ *   k_trace      persistent waves pull rays from a queue in HBM; each lane walks the packed 4-wide
+ *                BVH with its own stack in LDS (stack[depth][lane]: conflict-free per wave), idle
+ *                lanes are refilled from the queue.  NEAREST = bvhTraverse (Ray.cu:184-236) with
+ *                the reference's strict-'<' tie-break made tree-shape independent via reference
+ *                ranks; SHADOW = the predicates of Ray.cu:621-629 / 650-656.
+ *   k_shade      RayIntersection's bookkeeping (Ray.cu:479-525), wallIntersection (Ray.cu:238-457)
+ *                and Shade's light loop (Ray.cu:560-659), emitting compacted shadow / reflection
+ *                queues with wave-aggregated atomics.
+ *   k_resolve    Ray.cu:660 once the shadow results are in.
+ *   k_gen_primary GeneratePrimaryRays (Ray.cu:31-52) over this rank's image tiles, 8x8 pixels per wave.
+ *   k_convert    Ray.cu:724-731 on the device.
+ *   k_refit_*    refitTree (bvh.cu:288-400) as leaf pass + bottom-up pass with arrival counters.
+ */
+#include "kernels.h"
+#include "vec.h"
+
+namespace crt {
+
+#define CRT_DEV __device__ __forceinline__
+
+/* ------------------------------------------------------------------------------------------
+ * primitive tests
+ * ------------------------------------------------------------------------------------------ */
+struct GeomRec { float4 a, b, c; };
+
+CRT_DEV GeomRec load_geom(const Geom* g, uint32_t slot) {
+    const float4* p = reinterpret_cast<const float4*>(g + slot);
+    GeomRec r; r.a = p[0]; r.b = p[1]; r.c = p[2];
+    return r;
+}
+CRT_DEV bool is_sphere(const GeomRec& g) { return __float_as_uint(g.c.y) == kSphereTag; }
+
+/* intersectTriangle, Ray.cu:143-158, hit test only; Ng is the precomputed value of Ray.cu:145.
+ * `tlimit` is an early-out that cannot change which hit wins. */
+CRT_DEV bool tri_test(const GeomRec& g, const vec3& o, const vec3& d, float tlimit, float& tout) {
+    const vec3 v1(g.a.x, g.a.y, g.a.z), v2(g.a.w, g.b.x, g.b.y), v3(g.b.z, g.b.w, g.c.x), ng(g.c.y, g.c.z, g.c.w);
+    const float denom = dot(ng, d);
+    if (!(fabsf(denom) > .0001f)) return false;
+    const float t = dot((v1 - o), ng) / denom;
+    if (!(t >= -0.0001f)) return false;
+    if (t > tlimit) return false;
+    const vec3 X = o + t * d;
+    const float test1 = dot(cross((v2 - v1), (X - v1)), ng);
+    const float test2 = dot(cross((v3 - v2), (X - v2)), ng);
+    const float test3 = dot(cross((v1 - v3), (X - v3)), ng);
+    if (test1 >= 0.0f && test2 >= 0.0f && test3 >= 0.0f) { tout = t; return true; }
+    return false;
+}
+
+/* intersectSphere, Ray.cu:105-133: returns isectT; `tsmall` is the root used for the hit point */
+CRT_DEV bool sphere_test(const GeomRec& g, const vec3& o, const vec3& d, float& tout, float& tsmall) {
+    const float RAY_EPSILON = 0.000000001f;
+    const vec3 c(g.a.x, g.a.y, g.a.z);
+    const float a = dot(d, d);
+    const float b = 2.0f * dot(d, o - c);
+    const float cc = g.b.x + dot(o, o) + (-2.0f * dot(c, o)) - g.b.y;
+    const float disc = b * b - 4.0f * a * cc;
+    if (!(disc > RAY_EPSILON)) return false;
+    const float t = (-b - sqrtf(disc)) / (2.0f * a);
+    const float t2 = (-b + sqrtf(disc)) / (2.0f * a);
+    if (!(t2 > RAY_EPSILON)) return false;
+    tout = (t > RAY_EPSILON) ? t : t2;
+    tsmall = t;
+    return true;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * k_trace
+ * ------------------------------------------------------------------------------------------ */
+#define CSWAP(ta, la, tb, lb)                                   \
+    {                                                           \
+        const bool s_ = (tb) < (ta);                            \
+        const float t0_ = s_ ? (tb) : (ta), t1_ = s_ ? (ta) : (tb); \
+        const uint32_t l0_ = s_ ? (lb) : (la), l1_ = s_ ? (la) : (lb); \
+        ta = t0_; tb = t1_; la = l0_; lb = l1_;                 \
+    }
+
+template <int MODE, bool COUNT>
+__global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs A, LightsParam LP) {
+    __shared__ uint32_t s_stack[kStackDepth][kTraceBlock];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint32_t total = *A.count;
+    const uint32_t gthread = blockIdx.x * kTraceBlock + tid;
+    uint32_t* ovf = A.ovf + (size_t)gthread * (size_t)(A.ovf_depth > 0 ? A.ovf_depth : 0);
+
+    bool active = false;
+    bool exhausted = false;
+    vec3 o, d;
+    float ix = 0, iy = 0, iz = 0, ax = 0, ay = 0, az = 0, bx = 0, by = 0, bz = 0;
+    float tbest = 0;
+    int best = -1;
+    uint32_t cur = 0, ray = 0;
+    int sp = 0;
+    int found = 0;          /* SHADOW: a hit with t > 1e-9 exists */
+    int lightj = 0;
+    unsigned long long nbox = 0, ntri = 0, nsph = 0;
+
+    for (;;) {
+        /* ---- refill idle lanes from the queue ---- */
+        if (!exhausted) {
+            const unsigned long long idle = __ballot(!active);
+            const int nidle = __popcll(idle);
+            if (nidle >= kRefillMinIdle) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(A.next, (uint32_t)nidle);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (!active) {
+                    const uint32_t idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                    if (idx < total) {
+                        const float4 ro = A.rayO[idx], rd = A.rayD[idx];
+                        ray = idx;
+                        o = vec3(ro.x, ro.y, ro.z); d = vec3(rd.x, rd.y, rd.z);
+                        if (MODE == TRACE_SHADOW) { ray = __float_as_uint(ro.w); lightj = (int)__float_as_uint(rd.w); }
+                        /* clamped reciprocal: a zero component (the centre pixel column has
+                         * direction.x == 0 exactly) becomes +-1e20 instead of inf, so 0*inf never appears */
+                        float rx = 1.0f / d.x, ry = 1.0f / d.y, rz = 1.0f / d.z;
+                        if (!(fabsf(d.x) > 1e-20f)) rx = copysignf(1e20f, d.x);
+                        if (!(fabsf(d.y) > 1e-20f)) ry = copysignf(1e20f, d.y);
+                        if (!(fabsf(d.z) > 1e-20f)) rz = copysignf(1e20f, d.z);
+                        ix = rx; iy = ry; iz = rz;
+                        /* boxes are stored exact; the test pads them: lo' = lo - pad, hi' = hi + pad */
+                        const float px = 1e-3f + 1e-6f * (fabsf(o.x) + A.scene_abs);
+                        const float py = 1e-3f + 1e-6f * (fabsf(o.y) + A.scene_abs);
+                        const float pz = 1e-3f + 1e-6f * (fabsf(o.z) + A.scene_abs);
+                        ax = (o.x + px) * ix; bx = (o.x - px) * ix;
+                        ay = (o.y + py) * iy; by = (o.y - py) * iy;
+                        az = (o.z + pz) * iz; bz = (o.z - pz) * iz;
+                        tbest = 1000000000.0f; best = -1; cur = 0; sp = 0; found = 0;
+                        active = true;
+                    }
+                }
+                if (base + (uint32_t)nidle >= total) exhausted = true;
+            }
+        }
+        if (__ballot(active) == 0ull) break;
+
+        /* ---- traverse until enough lanes idle to be worth a refill ---- */
+        do {
+            if (active) {
+                bool finish = false;
+                if (!(cur & kLeafFlag)) {
+                    const float4* np = reinterpret_cast<const float4*>(A.sv.nodes + cur);
+                    const float4 lox = np[0], loy = np[1], loz = np[2], hix = np[3], hiy = np[4], hiz = np[5];
+                    const uint4 ch = reinterpret_cast<const uint4*>(np)[6];
+                    float tn0, tn1, tn2, tn3;
+#define SLAB(K, LX, LY, LZ, HX, HY, HZ, C)                                                      \
+    {                                                                                           \
+        const float x0 = fmaf(LX, ix, -ax), x1 = fmaf(HX, ix, -bx);                             \
+        const float y0 = fmaf(LY, iy, -ay), y1 = fmaf(HY, iy, -by);                             \
+        const float z0 = fmaf(LZ, iz, -az), z1 = fmaf(HZ, iz, -bz);                             \
+        const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), -1.0001e-4f)); \
+        const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tbest)); \
+        K = ((C) != kChildEmpty && tn <= tf) ? tn : INFINITY;                                   \
+        if (COUNT && (C) != kChildEmpty) nbox++;                                                \
+    }
+                    SLAB(tn0, lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, ch.x)
+                    SLAB(tn1, lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, ch.y)
+                    SLAB(tn2, lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, ch.z)
+                    SLAB(tn3, lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ch.w)
+#undef SLAB
+                    uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
+                    CSWAP(tn0, c0, tn1, c1)
+                    CSWAP(tn2, c2, tn3, c3)
+                    CSWAP(tn0, c0, tn2, c2)
+                    CSWAP(tn1, c1, tn3, c3)
+                    CSWAP(tn1, c1, tn2, c2)
+                    /* nearest child continues in `cur`; the others go on the stack far-first */
+#define PUSH(L)                                                                          \
+    {                                                                                    \
+        if (sp < kStackDepth) s_stack[sp][tid] = (L);                                    \
+        else if (sp - kStackDepth < A.ovf_depth) ovf[sp - kStackDepth] = (L);            \
+        else atomicOr(A.status, 1u);                                                     \
+        sp++;                                                                            \
+    }
+                    if (tn3 < INFINITY) PUSH(c3)
+                    if (tn2 < INFINITY) PUSH(c2)
+                    if (tn1 < INFINITY) PUSH(c1)
+#undef PUSH
+                    if (tn0 < INFINITY) cur = c0;
+                    else cur = kChildEmpty;
+                } else {
+                    const uint32_t start = cur & kLeafStartMask;
+                    const uint32_t cnt = ((cur >> kLeafCountShift) & 63u) + 1u;
+                    for (uint32_t p = start; p < start + cnt; p++) {
+                        const GeomRec g = load_geom(A.sv.geom, p);
+                        float t, tsm;
+                        bool hit;
+                        if (is_sphere(g)) { if (COUNT) nsph++; hit = sphere_test(g, o, d, t, tsm); }
+                        else { if (COUNT) ntri++; hit = tri_test(g, o, d, tbest, t); }
+                        if (!hit) continue;
+                        if (MODE == TRACE_NEAREST) {
+                            /* strict '<' as Ray.cu:199,216; equal t resolves to the primitive the
+                             * reference would have met first (lower rank in its leaf order) */
+                            if (t < tbest || (t == tbest && best >= 0 && A.sv.rank[p] < A.sv.rank[best])) { tbest = t; best = (int)p; }
+                        } else {
+                            if (LP.l[lightj].point) {           /* nearest t decides, Ray.cu:621-629 */
+                                if (t < tbest) { tbest = t; best = (int)p; }
+                            } else {                              /* Ray.cu:650-656: hit exists and min t > 1e-9 */
+                                if (!(t > 0.000000001f)) { found = 0; best = -2; finish = true; break; }
+                                found = 1; if (tbest > 0.000000001f) tbest = 0.000000001f;
+                            }
+                        }
+                    }
+                    cur = kChildEmpty;
+                }
+                if (cur == kChildEmpty && !finish) {
+                    if (sp == 0) finish = true;
+                    else {
+                        sp--;
+                        if (sp < kStackDepth) cur = s_stack[sp][tid];
+                        else if (sp - kStackDepth < A.ovf_depth) cur = ovf[sp - kStackDepth];
+                        else finish = true;          /* entry was dropped: status word already set, result invalid */
+                    }
+                }
+                if (finish) {
+                    if (MODE == TRACE_NEAREST) {
+                        A.hitSlot[ray] = best;
+                        A.hitT[ray] = tbest;
+                    } else {
+                        bool shadowed;
+                        if (LP.l[lightj].point) {
+                            shadowed = false;
+                            if (best >= 0) {
+                                const vec3 lpos(LP.l[lightj].position);
+                                const vec3 ipoint = o + tbest * d;
+                                const float ex = o.x - lpos.x, ey = o.y - lpos.y, ez = o.z - lpos.z;
+                                const float dtoLight = sqrtf(ex * ex + ey * ey + ez * ez);
+                                const float fx = ipoint.x - o.x, fy = ipoint.y - o.y, fz = ipoint.z - o.z;
+                                const float dtoLightIntersection = sqrtf(fx * fx + fy * fy + fz * fz);
+                                shadowed = dtoLight > dtoLightIntersection;
+                            }
+                        } else shadowed = (found != 0);
+                        if (shadowed) A.shflag[ray] = 1;
+                    }
+                    active = false;
+                }
+            }
+        } while (exhausted ? (__ballot(active) != 0ull) : (__popcll(__ballot(active)) > 64 - kRefillMinIdle));
+    }
+    if (COUNT) {
+        atomicAdd(&A.counters[0], nbox);
+        atomicAdd(&A.counters[1], ntri);
+        atomicAdd(&A.counters[2], nsph);
+    }
+}
+
+int trace_grid_blocks(int device) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) return 1024;
+    /* 32 KB of LDS stack per block -> 5 blocks of 4 waves per CU (160 KB LDS) */
+    return p.multiProcessorCount * 5;
+}
+
+void launch_trace(const TraceArgs& a, const LightsParam& lights, int mode, bool counting, int blocks, hipStream_t s) {
+    dim3 g(blocks), b(kTraceBlock);
+    if (mode == TRACE_NEAREST) {
+        if (counting) hipLaunchKernelGGL((k_trace<TRACE_NEAREST, true>), g, b, 0, s, a, lights);
+        else hipLaunchKernelGGL((k_trace<TRACE_NEAREST, false>), g, b, 0, s, a, lights);
+    } else {
+        if (counting) hipLaunchKernelGGL((k_trace<TRACE_SHADOW, true>), g, b, 0, s, a, lights);
+        else hipLaunchKernelGGL((k_trace<TRACE_SHADOW, false>), g, b, 0, s, a, lights);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * wave-aggregated queue append: one atomic per wave
+ * ------------------------------------------------------------------------------------------ */
+CRT_DEV uint32_t queue_slot(bool want, uint32_t* counter) {
+    const unsigned long long m = __ballot(want);
+    if (m == 0ull) return 0;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+/* ------------------------------------------------------------------------------------------
+ * k_gen_primary: GeneratePrimaryRays (Ray.cu:31-52).  Path q of this rank -> tile -> 8x8 pixel
+ * block per wave.  The reference's literal 720 (Ray.cu:37-38) becomes `width`.
+ * ------------------------------------------------------------------------------------------ */
+__global__ __launch_bounds__(256) void k_gen_primary(FrameParams P, FrameBuffers B, uint32_t* count) {
+    const uint32_t per_tile = (uint32_t)(P.tile_w * P.tile_h);
+    const uint32_t total = (uint32_t)P.ntiles_owned * per_tile;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t rounded = (total + 63u) & ~63u;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < rounded; q += stride) {
+        bool valid = q < total;
+        int px = 0, py = 0;
+        if (valid) {
+            const uint32_t tile = B.tile_ids[q / per_tile];
+            const uint32_t r = q % per_tile;
+            const uint32_t blk = r >> 6, l = r & 63u;
+            const uint32_t bpr = (uint32_t)P.tile_w >> 3;
+            px = (int)((tile % (uint32_t)P.tiles_x) * (uint32_t)P.tile_w + (blk % bpr) * 8u + (l & 7u));
+            py = (int)((tile / (uint32_t)P.tiles_x) * (uint32_t)P.tile_h + (blk / bpr) * 8u + (l >> 3));
+            valid = px < P.width && py < P.height;
+        }
+        const uint32_t k = queue_slot(valid, count);
+        if (!valid) continue;
+        const vec3 L(P.L), u(P.u), v(P.v), cam(P.cam);
+        vec3 pix;
+        if (P.spp_n <= 1) {
+            pix = (L + u * float(px) + v * float(py));
+        } else {        /* stratified sub-pixel offsets along u and v: an extension, SURVEY.md 8(d) config 5 */
+            const float ox = ((float)(P.sample % P.spp_n) + .5f) / (float)P.spp_n - .5f;
+            const float oy = ((float)(P.sample / P.spp_n) + .5f) / (float)P.spp_n - .5f;
+            pix = (L + u * (float(px) + ox) + v * (float(py) + oy));
+        }
+        const float xoffset = 0, yoffset = 0;
+        const vec3 sample = normalize(vec3(pix.x + xoffset, pix.y + yoffset, pix.z) - cam);
+        B.rayO[k] = make_float4(cam.x, cam.y, cam.z, 0.f);
+        B.rayD[k] = make_float4(sample.x, sample.y, sample.z, 0.f);
+        B.pix[k] = (uint32_t)(py * P.width + px);
+        B.coef[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+void launch_gen_primary(const FrameParams& fp, const FrameBuffers& fb, uint32_t* count, hipStream_t s) {
+    const uint64_t total = (uint64_t)fp.ntiles_owned * fp.tile_w * fp.tile_h;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_gen_primary, dim3(blocks), dim3(256), 0, s, fp, fb, count);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * k_shade
+ * ------------------------------------------------------------------------------------------ */
+struct WallDef { float n[3]; float p[3]; int kind; float diffuse[3]; float ambient[3]; };
+/* Ray.cu:238-457: floor, left, front, back, right, ceiling -- tested in this order, first
+ * in-bounds hit wins.  kind 0 bounds (z,x), 1 bounds (z,y), 2 bounds (x,y). */
+__constant__ WallDef c_walls[6] = {
+    {{0, 1, 0}, {0, -200.0f, 0}, 0, {1.0f, 0.2f, 0.2f}, {1.0f, 0.2f, 0.2f}},
+    {{1, 0, 0}, {-200.0f, 0, 0}, 1, {0.2f, 0.2f, 1.0f}, {0.2f, 0.2f, 1.0f}},
+    {{0, 0, 1}, {0, 0, -300.0f}, 2, {0.0f, 1.0f, 0.0f}, {0.0f, 1.0f, 0.0f}},
+    {{0, 0, -1}, {0, 0, 300.0f}, 2, {1.0f, 1.0f, 0.0f}, {1.0f, 1.0f, 0.0f}},
+    {{-1, 0, 0}, {200.0f, 0, 0}, 1, {0.2f, 0.2f, 1.0f}, {0.2f, 0.2f, 1.0f}},
+    {{0, -1, 0}, {0, 200.0f, 0}, 0, {0.9f, 0.9f, 0.9f}, {1.0f, 1.0f, 1.0f}},
+};
+
+__global__ __launch_bounds__(256) void k_shade(FrameParams P, FrameBuffers B, SceneView sv, LightsParam LP,
+                                                const uint32_t* count, uint32_t* next_count, uint32_t* shadow_count) {
+    const uint32_t total = *count;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t rounded = (total + 63u) & ~63u;
+    const int raytype = P.bounce > 0 ? 1 : 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += stride) {
+        const bool valid = i < total;
+        bool dead = !valid;
+        vec3 o, d, cin, P_, N, incident, rc, newcoef, diffuse, specular;
+        float shininess = 0.f;
+        uint32_t pix = 0;
+        if (valid) {
+            const float4 ro = B.rayO[i], rd = B.rayD[i], ci = B.coef[i];
+            o = vec3(ro.x, ro.y, ro.z); d = vec3(rd.x, rd.y, rd.z); cin = vec3(ci.x, ci.y, ci.z);
+            pix = B.pix[i];
+            const int slot = B.hitSlot[i];
+            int cap_id = -1;
+            if (slot >= 0) {
+                /* RayIntersection hit branch, Ray.cu:479-511, with the full intersect functions */
+                const GeomRec g = load_geom(sv.geom, (uint32_t)slot);
+                const float4* sp4 = reinterpret_cast<const float4*>(sv.shade + slot);
+                const float4 s0 = sp4[0], s1 = sp4[1], s2 = sp4[2];
+                vec3 X;
+                if (is_sphere(g)) {
+                    float t, tsm;
+                    sphere_test(g, o, d, t, tsm);
+                    const vec3 c(g.a.x, g.a.y, g.a.z);
+                    X = o + tsm * d;                                  /* Ray.cu:135 uses the smaller root */
+                    N = normalize((X - c) / g.a.w);
+                } else {
+                    /* intersectTriangle, Ray.cu:150-173 */
+                    const vec3 v1(g.a.x, g.a.y, g.a.z), v2(g.a.w, g.b.x, g.b.y), v3(g.b.z, g.b.w, g.c.x), ng(g.c.y, g.c.z, g.c.w);
+                    const float denom = dot(ng, d);
+                    const float t = dot((v1 - o), ng) / denom;
+                    X = o + t * d;
+                    const vec3 e0 = v2 - v1, e1 = v3 - v1, e2 = X - v1;
+                    const float d00 = dot(e0, e0), d01 = dot(e0, e1), d11 = dot(e1, e1), d20 = dot(e2, e0), d21 = dot(e2, e1);
+                    const float den = d00 * d11 - d01 * d01;
+                    const float vv = (d11 * d20 - d01 * d21) / den;
+                    const float ww = (d00 * d21 - d01 * d20) / den;
+                    const float uu = 1.0f - vv - ww;
+                    const vec3 n1(s0.x, s0.y, s0.z), n2(s0.w, s1.x, s1.y), n3(s1.z, s1.w, s2.x);
+                    N = normalize(uu * n1 + vv * n2 + ww * n3);
+                }
+                const Material m = sv.mats[__float_as_uint(s2.y)];
+                const vec3 refl(m.reflective), amb(m.ambient);
+                if (raytype == 0) {
+                    newcoef = refl; rc = vec3(1.0f, 1.0f, 1.0f);
+                    const vec3 c0 = 0.2f * amb;
+                    B.accum[pix] = make_float4(c0.x, c0.y, c0.z, 0.f);
+                } else { rc = cin; newcoef = cin * refl; }
+                P_ = X + N * 0.7f;
+                incident = d;
+                diffuse = vec3(m.diffuse); specular = vec3(m.specular); shininess = m.shininess;
+                cap_id = (int)sv.sidx[slot];
+            } else {
+                /* miss branch, Ray.cu:513-525 -> wallIntersection */
+                int w = -1;
+                for (int k = 0; k < 6 && w < 0; k++) {
+                    const vec3 up(c_walls[k].n);
+                    const float denom = dot(up, d);
+                    if (fabsf(denom) > .0001f) {
+                        const float t = dot((vec3(c_walls[k].p) - o), up) / denom;
+                        if (t >= -0.0001f) {
+                            const vec3 X = o + t * d;
+                            const float x = 200.0f, y = 200.0f, z = 300.0f;
+                            bool in;
+                            if (c_walls[k].kind == 0) in = X.z > -z && X.z < z && X.x > -x && X.x < x;
+                            else if (c_walls[k].kind == 1) in = X.z > -z && X.z < z && X.y < y && X.y > -y;
+                            else in = X.x > -x && X.x < x && X.y < y && X.y > -y;
+                            if (in) { w = k; P_ = X; N = up; }
+                        }
+                    }
+                }
+                if (w >= 0) {
+                    if (raytype == 0) {
+                        const vec3 c0 = 0.2f * vec3(c_walls[w].ambient);
+                        B.accum[pix] = make_float4(c0.x, c0.y, c0.z, 0.f);
+                        rc = vec3(1.0f, 1.0f, 1.0f);
+                    } else rc = cin;
+                    newcoef = vec3(0.f, 0.f, 0.f);        /* Ray.cu:257,262: nothing is reflected off a wall */
+                    incident = normalize(reflect(d, N));
+                    diffuse = vec3(c_walls[w].diffuse); specular = vec3(0.f, 0.f, 0.f); shininess = 2;
+                    cap_id = -2 - w;
+                } else {
+                    /* neither object nor wall: the reference shades an uninitialised Isect (NaN);
+                     * defined here as end of path, colour unchanged */
+                    dead = true;
+                    if (raytype == 0) B.accum[pix] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            if (P.capture) {
+                B.cap_ids[(size_t)P.bounce * B.cap_stride + pix] = cap_id;
+                B.cap_ts[(size_t)P.bounce * B.cap_stride + pix] = B.hitT[i];
+            }
+            B.rc[i] = make_float4(rc.x, rc.y, rc.z, dead ? 0.f : 1.f);
+        }
+
+        /* ---- Shade's light loop, Ray.cu:560-659 ---- */
+        vec3 direction, intersection = P_;
+        if (!dead) direction = normalize(incident);
+        for (int j = 0; j < LP.n; j++) {
+            const crt_light& l = LP.l[j];
+            bool want = false;
+            vec3 toLight, sorg;
+            if (!dead) {
+                vec3 reflectFromLight;
+                float distance;
+                uint8_t flag = 0;
+                if (l.point) {
+                    const vec3 lpos(l.position);
+                    const float ex = intersection.x - lpos.x, ey = intersection.y - lpos.y, ez = intersection.z - lpos.z;
+                    const float dd = sqrtf(ex * ex + ey * ey + ez * ez);
+                    distance = 1.0f / (l.constantTerm + l.linearTerm * dd + l.quadraticTerm * (dd * dd));
+                    if (distance > 1.5f) distance = .5f;
+                    toLight = normalize(lpos - intersection);
+                    reflectFromLight = -toLight;
+                    intersection = intersection + .01f * N;           /* cumulative, Ray.cu:620 */
+                    want = true;
+                } else {
+                    distance = 1.0f;
+                    toLight = -normalize(vec3(l.direction));
+                    reflectFromLight = normalize(vec3(l.direction));
+                    const float dotP = dot(reflectFromLight, N);
+                    if ((double)dotP > -0.00001) flag = 1;            /* faces away: shadowed without a ray */
+                    else want = true;
+                }
+                sorg = intersection;
+                const float sdot = dot(reflect(reflectFromLight, N), -direction);
+                const float spec = (float)pow((double)sdot, (double)shininess);
+                const vec3 X = (.6f * diffuse * gmax(dot(toLight, N), 0.0f) + .2f * specular * spec);
+                B.contrib[(size_t)j * B.cap + i] = make_float4(X.x, X.y, X.z, distance);
+                B.shflag[(size_t)j * B.cap + i] = flag;
+            }
+            const uint32_t ks = queue_slot(want, shadow_count);
+            if (want) {
+                B.shO[ks] = make_float4(sorg.x, sorg.y, sorg.z, __uint_as_float((uint32_t)((size_t)j * B.cap + i)));
+                B.shD[ks] = make_float4(toLight.x, toLight.y, toLight.z, __uint_as_float((uint32_t)j));
+            }
+        }
+
+        /* ---- reflected ray, Ray.cu:494-496 / 519-520; paths whose coefficient is zero end here ---- */
+        const bool emit = !dead && (P.bounce + 1 < P.bounces) && (newcoef.x != 0.f || newcoef.y != 0.f || newcoef.z != 0.f);
+        const uint32_t kn = queue_slot(emit, next_count);
+        if (emit) {
+            const vec3 rdir = normalize(reflect(d, N));
+            B.nrayO[kn] = make_float4(P_.x, P_.y, P_.z, 0.f);
+            B.nrayD[kn] = make_float4(rdir.x, rdir.y, rdir.z, 0.f);
+            B.ncoef[kn] = make_float4(newcoef.x, newcoef.y, newcoef.z, 0.f);
+            B.npix[kn] = pix;
+        }
+    }
+}
+
+void launch_shade(const FrameParams& fp, const FrameBuffers& fb, const SceneView& sv, const LightsParam& lights,
+                  const uint32_t* count, uint32_t* next_count, uint32_t* shadow_count, hipStream_t s) {
+    hipLaunchKernelGGL(k_shade, dim3(4096), dim3(256), 0, s, fp, fb, sv, lights, count, next_count, shadow_count);
+}
+
+/* isectPoints[i].color += reflectionCoef * color (Ray.cu:660), colour summed over lights in order
+ * with `distance * 0` for shadowed lights (Ray.cu:629,655) */
+__global__ __launch_bounds__(256) void k_resolve(FrameBuffers B, LightsParam LP, const uint32_t* count) {
+    const uint32_t total = *count;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const float4 rc4 = B.rc[i];
+        if (rc4.w == 0.f) continue;
+        vec3 color;
+        for (int j = 0; j < LP.n; j++) {
+            const float4 c = B.contrib[(size_t)j * B.cap + i];
+            float distance = c.w;
+            if (B.shflag[(size_t)j * B.cap + i]) distance = distance * 0;
+            color += distance * vec3(LP.l[j].color) * vec3(c.x, c.y, c.z);
+        }
+        const uint32_t pix = B.pix[i];
+        float4 a = B.accum[pix];
+        vec3 acc(a.x, a.y, a.z);
+        acc += vec3(rc4.x, rc4.y, rc4.z) * color;
+        B.accum[pix] = make_float4(acc.x, acc.y, acc.z, 0.f);
+    }
+}
+
+void launch_resolve(const FrameBuffers& fb, const LightsParam& lights, const uint32_t* count, hipStream_t s) {
+    hipLaunchKernelGGL(k_resolve, dim3(4096), dim3(256), 0, s, fb, lights, count);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * output conversion, Ray.cu:724-731: *255, clamp, truncate, BGR, row 0 = bottom
+ * ------------------------------------------------------------------------------------------ */
+CRT_DEV bool tile_pixel(const FrameParams& P, const uint32_t* tile_ids, uint32_t q, uint32_t& pixel) {
+    const uint32_t per_tile = (uint32_t)(P.tile_w * P.tile_h);
+    const uint32_t tile = tile_ids[q / per_tile];
+    const uint32_t r = q % per_tile;
+    const uint32_t px = (tile % (uint32_t)P.tiles_x) * (uint32_t)P.tile_w + r % (uint32_t)P.tile_w;
+    const uint32_t py = (tile / (uint32_t)P.tiles_x) * (uint32_t)P.tile_h + r / (uint32_t)P.tile_w;
+    pixel = py * (uint32_t)P.width + px;
+    return px < (uint32_t)P.width && py < (uint32_t)P.height;
+}
+
+__global__ __launch_bounds__(256) void k_convert(FrameParams P, FrameBuffers B, const float4* sum, uint8_t* bgr) {
+    const uint32_t total = (uint32_t)P.ntiles_owned * (uint32_t)(P.tile_w * P.tile_h);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
+        uint32_t pixel;
+        if (!tile_pixel(P, B.tile_ids, q, pixel)) continue;
+        vec3 c;
+        if (sum) { const float4 s = sum[pixel]; const float inv = (float)(P.spp_n * P.spp_n); c = vec3(s.x / inv, s.y / inv, s.z / inv); }
+        else { const float4 a = B.accum[pixel]; c = vec3(a.x, a.y, a.z); }
+        c = c * 255.0f;
+        c = vec3(gclamp(c.x, 0.0f, 255.0f), gclamp(c.y, 0.0f, 255.0f), gclamp(c.z, 0.0f, 255.0f));
+        bgr[(size_t)pixel * 3] = (uint8_t)c.z;
+        bgr[(size_t)pixel * 3 + 1] = (uint8_t)c.y;
+        bgr[(size_t)pixel * 3 + 2] = (uint8_t)c.x;
+    }
+}
+void launch_convert(const FrameParams& fp, const FrameBuffers& fb, const float4* sum, uint8_t* bgr, hipStream_t s) {
+    hipLaunchKernelGGL(k_convert, dim3(2048), dim3(256), 0, s, fp, fb, sum, bgr);
+}
+
+__global__ __launch_bounds__(256) void k_spp_accumulate(FrameParams P, FrameBuffers B, float4* sum) {
+    const uint32_t total = (uint32_t)P.ntiles_owned * (uint32_t)(P.tile_w * P.tile_h);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
+        uint32_t pixel;
+        if (!tile_pixel(P, B.tile_ids, q, pixel)) continue;
+        const float4 a = B.accum[pixel];
+        float4 s = P.sample == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : sum[pixel];
+        s.x += a.x; s.y += a.y; s.z += a.z;
+        sum[pixel] = s;
+    }
+}
+void launch_spp_accumulate(const FrameParams& fp, const FrameBuffers& fb, float4* sum, hipStream_t s) {
+    hipLaunchKernelGGL(k_spp_accumulate, dim3(2048), dim3(256), 0, s, fp, fb, sum);
+}
+
+/* tile-major packing of this rank's pixels for the framebuffer gather */
+__global__ __launch_bounds__(256) void k_tiles_copy(FrameParams P, const uint32_t* tile_ids, int ntiles, const uint8_t* src,
+                                                     uint8_t* dst, int to_packed) {
+    const uint32_t total = (uint32_t)ntiles * (uint32_t)(P.tile_w * P.tile_h);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
+        uint32_t pixel;
+        if (!tile_pixel(P, tile_ids, q, pixel)) continue;
+        for (int c = 0; c < 3; c++) {
+            if (to_packed) dst[(size_t)q * 3 + c] = src[(size_t)pixel * 3 + c];
+            else dst[(size_t)pixel * 3 + c] = src[(size_t)q * 3 + c];
+        }
+    }
+}
+void launch_tiles_copy(const FrameParams& fp, const uint32_t* tile_ids, int ntiles, const uint8_t* src, uint8_t* dst,
+                       int to_packed, hipStream_t s) {
+    hipLaunchKernelGGL(k_tiles_copy, dim3(2048), dim3(256), 0, s, fp, tile_ids, ntiles, src, dst, to_packed);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * scene packing: crt_prim (scene order) -> Geom/Shade records at their slots
+ * ------------------------------------------------------------------------------------------ */
+__global__ __launch_bounds__(256) void k_pack_prims(const crt_prim* prims, const uint32_t* matid, const uint32_t* slot_of,
+                                                     uint32_t n, Geom* geom, Shade* shade) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const crt_prim& s = prims[i];
+    const uint32_t slot = slot_of[i];
+    float4* g = reinterpret_cast<float4*>(geom + slot);
+    float4* h = reinterpret_cast<float4*>(shade + slot);
+    if (s.type == 0) {
+        const vec3 c(s.position);
+        g[0] = make_float4(c.x, c.y, c.z, s.radius);
+        g[1] = make_float4(dot(c, c), s.radius * s.radius, 0.f, 0.f);     /* Ray.cu:110 terms that do not depend on the ray */
+        g[2] = make_float4(0.f, __uint_as_float(kSphereTag), 0.f, 0.f);
+        h[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        h[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        const vec3 v1(s.v1), v2(s.v2), v3(s.v3);
+        vec3 ng = normalize(cross((v2 - v1), (v3 - v1)));                 /* Ray.cu:145, same operation order */
+        if (ng.x != ng.x) ng.x = __uint_as_float(0x7fc00000u);           /* degenerate: never the sphere tag */
+        g[0] = make_float4(v1.x, v1.y, v1.z, v2.x);
+        g[1] = make_float4(v2.y, v2.z, v3.x, v3.y);
+        g[2] = make_float4(v3.z, ng.x, ng.y, ng.z);
+        h[0] = make_float4(s.v1Norm[0], s.v1Norm[1], s.v1Norm[2], s.v2Norm[0]);
+        h[1] = make_float4(s.v2Norm[1], s.v2Norm[2], s.v3Norm[0], s.v3Norm[1]);
+    }
+    h[2] = make_float4(s.type == 0 ? 0.f : s.v3Norm[2], __uint_as_float(matid[i]), 0.f, 0.f);
+}
+void launch_pack_prims(const crt_prim* d_prims, const uint32_t* d_matid, const uint32_t* slot_of, uint32_t n, Geom* geom,
+                       Shade* shade, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_pack_prims, dim3((n + 255) / 256), dim3(256), 0, s, d_prims, d_matid, slot_of, n, geom, shade);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * refit (refitTree, bvh.cu:288-400): pass 1 recomputes every leaf child's box from its
+ * primitives; pass 2 climbs from the nodes that have no internal children, the last child to
+ * arrive at a parent (agent-scope arrival counter) carries on.  grow_only keeps the reference's
+ * "boxes never shrink" rule; min/max are exact, so the result is order independent.
+ * ------------------------------------------------------------------------------------------ */
+__global__ __launch_bounds__(256) void k_refit_leaves(Node4* nodes, uint32_t nnodes, const Geom* geom, int grow_only) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= nnodes * 4u) return;
+    Node4& nd = nodes[id >> 2];
+    const int k = (int)(id & 3u);
+    const uint32_t link = nd.child[k];
+    if (link == kChildEmpty || !(link & kLeafFlag)) return;
+    const uint32_t start = link & kLeafStartMask, cnt = ((link >> kLeafCountShift) & 63u) + 1u;
+    float lo[3], hi[3];
+    if (grow_only) { lo[0] = nd.lox[k]; lo[1] = nd.loy[k]; lo[2] = nd.loz[k]; hi[0] = nd.hix[k]; hi[1] = nd.hiy[k]; hi[2] = nd.hiz[k]; }
+    else { lo[0] = lo[1] = lo[2] = 3.402823466e+38f; hi[0] = hi[1] = hi[2] = -3.402823466e+38f; }
+    for (uint32_t p = start; p < start + cnt; p++) {
+        const GeomRec g = load_geom(geom, p);
+        if (is_sphere(g)) {
+            const float c[3] = {g.a.x, g.a.y, g.a.z};
+            for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], c[a] - g.a.w); hi[a] = fmaxf(hi[a], c[a] + g.a.w); }
+        } else {
+            const float vx[3] = {g.a.x, g.a.w, g.b.z}, vy[3] = {g.a.y, g.b.x, g.b.w}, vz[3] = {g.a.z, g.b.y, g.c.x};
+            for (int q = 0; q < 3; q++) {
+                lo[0] = fminf(lo[0], vx[q]); hi[0] = fmaxf(hi[0], vx[q]);
+                lo[1] = fminf(lo[1], vy[q]); hi[1] = fmaxf(hi[1], vy[q]);
+                lo[2] = fminf(lo[2], vz[q]); hi[2] = fmaxf(hi[2], vz[q]);
+            }
+        }
+    }
+    nd.lox[k] = lo[0]; nd.loy[k] = lo[1]; nd.loz[k] = lo[2];
+    nd.hix[k] = hi[0]; nd.hiy[k] = hi[1]; nd.hiz[k] = hi[2];
+}
+
+__global__ __launch_bounds__(256) void k_refit_up(Node4* nodes, uint32_t nnodes, uint32_t* arrive, float* root_box, int grow_only) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= nnodes) return;
+    if (nodes[id].n_internal != 0) return;
+    uint32_t cur = id;
+    for (int guard = 0; guard < 4096; guard++) {
+        const Node4& nd = nodes[cur];
+        float lo[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
+        float hi[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+        for (int k = 0; k < 4; k++) {
+            lo[0] = fminf(lo[0], nd.lox[k]); lo[1] = fminf(lo[1], nd.loy[k]); lo[2] = fminf(lo[2], nd.loz[k]);
+            hi[0] = fmaxf(hi[0], nd.hix[k]); hi[1] = fmaxf(hi[1], nd.hiy[k]); hi[2] = fmaxf(hi[2], nd.hiz[k]);
+        }
+        const uint32_t parent = nd.parent;
+        if (parent == kChildEmpty) {
+            if (grow_only) {
+                lo[0] = fminf(lo[0], root_box[0]); hi[0] = fmaxf(hi[0], root_box[1]);
+                lo[1] = fminf(lo[1], root_box[2]); hi[1] = fmaxf(hi[1], root_box[3]);
+                lo[2] = fminf(lo[2], root_box[4]); hi[2] = fmaxf(hi[2], root_box[5]);
+            }
+            root_box[0] = lo[0]; root_box[1] = hi[0]; root_box[2] = lo[1]; root_box[3] = hi[1]; root_box[4] = lo[2]; root_box[5] = hi[2];
+            return;
+        }
+        Node4& pn = nodes[parent];
+        const int k = (int)nd.parent_slot;
+        if (grow_only) {
+            lo[0] = fminf(lo[0], pn.lox[k]); lo[1] = fminf(lo[1], pn.loy[k]); lo[2] = fminf(lo[2], pn.loz[k]);
+            hi[0] = fmaxf(hi[0], pn.hix[k]); hi[1] = fmaxf(hi[1], pn.hiy[k]); hi[2] = fmaxf(hi[2], pn.hiz[k]);
+        }
+        pn.lox[k] = lo[0]; pn.loy[k] = lo[1]; pn.loz[k] = lo[2];
+        pn.hix[k] = hi[0]; pn.hiy[k] = hi[1]; pn.hiz[k] = hi[2];
+        const uint32_t need = pn.n_internal;
+        /* publish, then arrive: stores drained, agent-scope release, relaxed agent-scope ticket */
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t prev = __hip_atomic_fetch_add(&arrive[parent], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev + 1u < need) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        cur = parent;
+    }
+}
+
+void launch_refit(Node4* nodes, uint32_t nnodes, const Geom* geom, uint32_t* arrive, float* root_box, int grow_only,
+                  hipStream_t s) {
+    if (nnodes == 0) return;
+    hipMemsetAsync(arrive, 0, sizeof(uint32_t) * nnodes, s);
+    hipLaunchKernelGGL(k_refit_leaves, dim3((nnodes * 4u + 255u) / 256u), dim3(256), 0, s, nodes, nnodes, geom, grow_only);
+    hipLaunchKernelGGL(k_refit_up, dim3((nnodes + 255u) / 256u), dim3(256), 0, s, nodes, nnodes, arrive, root_box, grow_only);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * small helpers for the parity hooks
+ * ------------------------------------------------------------------------------------------ */
+__global__ void k_slots_to_scene(const int32_t* slots, const uint32_t* sidx, int32_t* out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = slots[i] >= 0 ? (int32_t)sidx[slots[i]] : -1;
+}
+void launch_slots_to_scene(const int32_t* slots, const uint32_t* sidx, int32_t* out, uint32_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_slots_to_scene, dim3((n + 255) / 256), dim3(256), 0, s, slots, sidx, out, n);
+}
+__global__ void k_pack_rays(const float* od, uint32_t n, float4* rayO, float4* rayD) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    rayO[i] = make_float4(od[6 * i], od[6 * i + 1], od[6 * i + 2], __uint_as_float(i));
+    rayD[i] = make_float4(od[6 * i + 3], od[6 * i + 4], od[6 * i + 5], 0.f);
+}
+void launch_pack_rays(const float* org_dir, uint32_t n, float4* rayO, float4* rayD, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_pack_rays, dim3((n + 255) / 256), dim3(256), 0, s, org_dir, n, rayO, rayD);
+}
+
+}  // namespace crt

@@ -162,6 +162,14 @@ void crt_camera_default(crt_camera*);                                           
 int crt_animate_host(crt_prim* prims, int n);                                          /* main.cu:545-573 */
 int crt_write_bmp(const char* path, const unsigned char* bgr, int width, int height); /* headless output */
 
+/* Host-only view of the two BVH builders (no device needed): what crt_bvh_build packs and uploads.
+ * Two-call pattern: pass NULL arrays to get *nnodes, then arrays with cap_nodes >= *nnodes.
+ * child_boxes: nnodes*4*6 floats (minX,maxX,minY,maxY,minZ,maxZ per child); child_links: nnodes*4;
+ * parents: nnodes*2 (parent node, slot in parent); slot_to_scene, rank_of_scene: n each. */
+int crt_host_bvh(const crt_prim* prims, int n, int mode, int32_t* nnodes, int32_t* depth, float* root_box6,
+                 float* child_boxes, uint32_t* child_links, uint32_t* parents, uint32_t* slot_to_scene,
+                 uint32_t* rank_of_scene, int cap_nodes);
+
 #ifdef __cplusplus
 }
 #endif

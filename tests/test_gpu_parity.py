@@ -1,0 +1,274 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Bar (BASELINE.json north_star): nearest-hit primitive ids bit-exact except stated grazing/tie
+cases, hit t within 1e-4 relative, 8-bit BGR within 1 LSB.  Both sides evaluate the reference's
+float expressions without FMA contraction, so in practice ids and t are compared for equality
+and the tests report (and bound) the number of exceptions.
+"""
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+
+T_RTOL = 1e-4          # north_star: hit t within 1e-4 relative
+LSB = 1                # north_star: 8-bit colour within 1 LSB
+GRAZING_FRACTION = 2e-4  # bound on rays allowed in the stated exception classes
+
+
+@pytest.fixture(scope="module")
+def crt():
+    import cudaraytracer_amd as m
+    return m
+
+
+@pytest.fixture(scope="module")
+def teapot(crt):
+    prims = crt.scene_teapot(with_sphere=True)
+    ctx = crt.Context(0)
+    ctx.set_scene(prims)
+    ctx.set_lights(crt.default_lights())
+    ctx.build(0)
+    sc = orc.Scene(prims)
+    sc.build()
+    yield prims, ctx, sc
+    ctx.close()
+    sc.close()
+
+
+def compare_hits(ids_g, ts_g, ids_o, ts_o, what):
+    n = len(ids_o)
+    bad_id = ids_g != ids_o
+    hit = (ids_o >= 0) & ~bad_id
+    rel = np.abs(ts_g[hit] - ts_o[hit]) / np.maximum(np.abs(ts_o[hit]), 1e-30)
+    n_t = int((rel > T_RTOL).sum())
+    print(f"{what}: rays={n} hits={int((ids_o >= 0).sum())} id_mismatch={int(bad_id.sum())} "
+          f"t_exact={int((ts_g[hit] == ts_o[hit]).sum())}/{int(hit.sum())} t_out_of_tol={n_t}")
+    assert bad_id.sum() <= max(2, GRAZING_FRACTION * n), f"{what}: {bad_id.sum()} nearest-hit id mismatches"
+    assert n_t == 0, f"{what}: {n_t} hit distances beyond {T_RTOL} relative"
+    return int(bad_id.sum())
+
+
+def test_trace_teapot_primary(crt, teapot):
+    prims, ctx, sc = teapot
+    cam, tgt = crt.default_camera()
+    rays = orc.primary_rays(cam, tgt, 720, 360)
+    ids_g, ts_g = ctx.trace(rays)
+    ids_o, ts_o = sc.trace(rays)
+    assert (ids_o >= 0).sum() > 25000
+    compare_hits(ids_g, ts_g, ids_o, ts_o, "teapot primary 720x360")
+
+
+def test_trace_random_rays_both_topologies(crt, teapot):
+    prims, ctx, sc = teapot
+    rng = np.random.default_rng(7)
+    n = 200000
+    o = rng.uniform(-150, 150, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    # a quarter of the rays aim at the teapot so that hits are plentiful, some start inside boxes
+    tgt = rng.uniform(-40, 40, (n // 4, 3)).astype(np.float32)
+    dd = tgt - o[: n // 4]
+    d[: n // 4] = dd / np.linalg.norm(dd, axis=1, keepdims=True)
+    # axis-parallel directions: zero components exercise the slab test's division by zero
+    d[-300:-200] = [1, 0, 0]
+    d[-200:-100] = [0, -1, 0]
+    d[-100:] = [0, 0, 1]
+    rays = np.concatenate([o, d.astype(np.float32)], axis=1)
+    ids_o, ts_o = sc.trace(rays)
+    ids_g, ts_g = ctx.trace(rays)
+    compare_hits(ids_g, ts_g, ids_o, ts_o, "random rays, wide BVH")
+    # the same kernel on the reference's own topology (mean-centroid split, 64-primitive leaves)
+    ctx2 = crt.Context(0)
+    ctx2.set_scene(prims)
+    ctx2.build(1)
+    ids_r, ts_r = ctx2.trace(rays)
+    ctx2.close()
+    compare_hits(ids_r, ts_r, ids_o, ts_o, "random rays, reference topology")
+
+
+def test_shadow_predicate(crt, teapot):
+    prims, ctx, sc = teapot
+    rng = np.random.default_rng(11)
+    n = 100000
+    o = rng.uniform(-100, 100, (n, 3)).astype(np.float32)
+    l = -np.array([2, -1, -1], np.float32)
+    d = np.tile(l / np.linalg.norm(l), (n, 1)).astype(np.float32)
+    rays = np.concatenate([o, d], axis=1)
+    ids_o, ts_o = sc.trace(rays)
+    want = ((ids_o >= 0) & (ts_o > np.float32(1e-9))).astype(np.uint8)    # Ray.cu:652-656
+    got = ctx.trace_shadow(rays)
+    assert want.sum() > 1000
+    assert int((want != got).sum()) <= 2, f"{int((want != got).sum())} shadow predicate mismatches"
+
+
+def render_pair(crt, ctx, sc, w, h, bounces, lights):
+    cam, tgt = crt.default_camera()
+    ctx.set_capture(True)
+    p = crt.default_params(width=w, height=h, bounces=bounces)
+    g = ctx.render(cam, tgt, p)
+    o = sc.render(lights, cam, tgt, w, h, bounces, nthreads=16, want_color=True, want_ids=True)
+    return g, o, p
+
+
+def check_image(g, o, what, max_bad=0):
+    diff = np.abs(g.astype(np.int32) - o["bgr"].astype(np.int32))
+    n1 = int((diff.max(axis=2) == 1).sum())
+    nbad = int((diff.max(axis=2) > LSB).sum())
+    print(f"{what}: pixels={diff.shape[0] * diff.shape[1]} exact={int((diff.max(axis=2) == 0).sum())} "
+          f"off_by_1={n1} beyond_1_lsb={nbad}")
+    assert nbad <= max_bad, f"{what}: {nbad} pixels differ by more than {LSB} LSB"
+
+
+@pytest.mark.parametrize("bounces", [1, 2, 4])
+def test_render_teapot_720x360(crt, teapot, bounces):
+    """configs[0] (bounces=1) and the reference default (2) / reflection depth 3 (4) at the
+    reference's own resolution."""
+    prims, ctx, sc = teapot
+    lights = crt.default_lights()
+    g, o, p = render_pair(crt, ctx, sc, 720, 360, bounces, lights)
+    npix = 720 * 360
+    total_bad = 0
+    for b in range(bounces):
+        ids_g, ts_g = ctx.capture(b, npix)
+        ids_o, ts_o = o["ids"][b], o["ts"][b]
+        traced = ids_g != -9            # the GPU ends paths whose coefficient is zero
+        total_bad += compare_hits(ids_g[traced], ts_g[traced], ids_o[traced], ts_o[traced], f"bounce {b}")
+    # a grazing id flip changes its pixel legitimately: allow as many pixels as ids flipped
+    check_image(g, o, f"teapot 720x360 bounces={bounces}", max_bad=total_bad)
+    st = ctx.stats()
+    live = sc.stats(reset=True)["live_traversals"]
+    issued = st["rays_primary"] + st["rays_shadow"] + st["rays_reflect"]
+    print("rays issued gpu", issued, "oracle live", live)
+    assert abs(issued - live) <= 4 + 8 * total_bad
+
+
+def test_render_teapot_1080p_depth3(crt, teapot):
+    """configs[1]: teapot3.obj 1920x1080, reflection depth 3 (bounces=4)."""
+    prims, ctx, sc = teapot
+    g, o, p = render_pair(crt, ctx, sc, 1920, 1080, 4, crt.default_lights())
+    check_image(g, o, "teapot 1920x1080 bounces=4", max_bad=8)
+    sc.stats(reset=True)
+
+
+def test_point_light_and_odd_size(crt, teapot):
+    prims, ctx, sc = teapot
+    lights = np.zeros(3, crt.LIGHT_DTYPE)
+    lights[:2] = crt.default_lights()
+    l2 = lights[2]          # main.cu:472-479 (declared in the reference, never pushed)
+    l2["point"] = 1; l2["position"] = (4, 3, -4); l2["color"] = (.5, .5, .5)
+    l2["constantTerm"] = 0.25; l2["linearTerm"] = 0.003372407; l2["quadraticTerm"] = 0.000045492
+    lights = lights[[2, 0, 1]]    # point light first: its cumulative .01*N nudge then moves the later shadow origins
+    ctx.set_lights(lights)
+    try:
+        g, o, p = render_pair(crt, ctx, sc, 333, 205, 3, lights)   # not a multiple of the 32x32 tile
+        check_image(g, o, "point light 333x205 bounces=3", max_bad=4)
+    finally:
+        ctx.set_lights(crt.default_lights())
+        sc.stats(reset=True)
+
+
+def test_spheres_scene_and_refit(crt):
+    """configs[2] at test size: moving spheres, refit every frame, rebuild every 20th."""
+    prims = crt.scene_spheres(2048, seed=1)
+    lights = crt.default_lights()
+    cam, tgt = crt.default_camera()
+    ctx = crt.Context(0)
+    ctx.set_scene(prims); ctx.set_lights(lights); ctx.build(0)
+    sc = orc.Scene(prims); sc.build()
+    p = crt.default_params(width=480, height=270, bounces=2)
+    try:
+        for frame in range(23):
+            if frame > 0:
+                crt.animate_host(prims)
+                sc.animate()
+                assert prims.tobytes() == sc.prims().tobytes(), "animation step differs from the oracle"
+                if frame % 20 == 0:
+                    ctx.set_scene(prims); ctx.build(0); sc.build()
+                else:
+                    ctx.update_scene(prims); ctx.refit(False); sc.refit()
+            if frame in (0, 1, 5, 19, 20, 22):
+                g = ctx.render(cam, tgt, p)
+                o = sc.render(lights, cam, tgt, 480, 270, 2, nthreads=16)
+                check_image(g, o, f"spheres frame {frame}", max_bad=6)
+    finally:
+        ctx.close(); sc.close()
+
+
+def match_reference_tree(dump, root, boxes, links):
+    """Walk the oracle's pointer tree and the packed reference-topology nodes together; yield
+    (oracle node index, packed box)."""
+    out = []
+
+    def rec(oi, packed_box, link):
+        out.append((oi, packed_box))
+        if dump["isleaf"][oi]:
+            return
+        node = int(link)
+        for k, child in enumerate((dump["left"][oi], dump["right"][oi])):
+            rec(child, boxes[node, k], links[node, k])
+    if dump["isleaf"][0]:
+        rec(0, boxes[0, 0], links[0, 0])
+    else:
+        rec(0, root, 0)
+    return out
+
+
+def test_refit_kernel_equals_refitTree(crt, teapot):
+    """A11: bottom-up refit kernel in grow-only mode on the reference's topology equals
+    refitTree (bvh.cu:288-400) bit for bit, over several animated frames."""
+    prims = crt.scene_teapot(with_sphere=True)
+    ctx = crt.Context(0)
+    ctx.set_scene(prims); ctx.build(1)
+    sc = orc.Scene(prims); sc.build()
+    try:
+        for frame in range(6):
+            root, boxes, links = ctx.dump()
+            d = sc.dump()
+            pairs = match_reference_tree(d, root, boxes, links)
+            assert len(pairs) == len(d["boxes"])
+            for oi, pb in pairs:
+                assert np.array_equal(d["boxes"][oi], pb), f"frame {frame}: box of oracle node {oi} differs"
+            crt.animate_host(prims); sc.animate()
+            ctx.update_scene(prims); ctx.refit(True); sc.refit()
+    finally:
+        ctx.close(); sc.close()
+
+
+def test_refit_tight_boxes_contain_primitives(crt):
+    prims = crt.scene_spheres(5000, seed=3)
+    ctx = crt.Context(0)
+    ctx.set_scene(prims); ctx.build(0)
+    try:
+        for _ in range(3):
+            crt.animate_host(prims)
+        ctx.update_scene(prims); ctx.refit(False)
+        root, boxes, links = ctx.dump()
+        host = crt.host_bvh(prims, 0)       # same topology (built before the motion? no: rebuilt) -> only check containment
+        lo = prims["position"] - prims["radius"][:, None]
+        hi = prims["position"] + prims["radius"][:, None]
+        assert np.all(root[0::2] <= lo.min(axis=0)) and np.all(root[1::2] >= hi.max(axis=0))
+        assert host["depth"] > 0
+    finally:
+        ctx.close()
+
+
+def test_soup_small_image_parity(crt):
+    """configs[3] at test size: random triangle soup, incoherent secondary rays."""
+    prims = crt.scene_soup(30000, seed=1)
+    lights = crt.default_lights()
+    ctx = crt.Context(0)
+    ctx.set_scene(prims); ctx.set_lights(lights); ctx.build(0)
+    sc = orc.Scene(prims); sc.build()
+    try:
+        g, o, p = render_pair(crt, ctx, sc, 640, 360, 3, lights)
+        npix = 640 * 360
+        bad = 0
+        for b in range(3):
+            ids_g, ts_g = ctx.capture(b, npix)
+            traced = ids_g != -9
+            bad += compare_hits(ids_g[traced], ts_g[traced], o["ids"][b][traced], o["ts"][b][traced], f"soup bounce {b}")
+        check_image(g, o, "soup 30k 640x360 bounces=3", max_bad=bad)
+    finally:
+        ctx.close(); sc.close()
