@@ -48,8 +48,10 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_reflect", C.c_uint64),
                 ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64), ("sph_tests", C.c_uint64),
+                ("box_tests_shadow", C.c_uint64), ("tri_tests_shadow", C.c_uint64), ("sph_tests_shadow", C.c_uint64),
                 ("ms_total", C.c_double), ("ms_trace", C.c_double), ("ms_shade", C.c_double), ("ms_other", C.c_double),
-                ("ms_trace_nearest", C.c_double), ("launches_trace_nearest", C.c_int32),
+                ("ms_trace_nearest", C.c_double), ("ms_trace_shadow", C.c_double),
+                ("launches_trace_nearest", C.c_int32), ("launches_trace_shadow", C.c_int32),
                 ("nodes", C.c_int32), ("prims", C.c_int32), ("depth", C.c_int32), ("leaves", C.c_int32),
                 ("ms_build_host", C.c_double), ("ms_refit", C.c_double), ("scene_bytes", C.c_uint64)]
 

@@ -276,13 +276,13 @@ crt_ctx* crt_create(int device, int* err) {
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void**)&c->d_status, 4) != hipSuccess ||
-        hipMalloc((void**)&c->d_testctr, 3 * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc((void**)&c->d_testctr, 6 * sizeof(unsigned long long)) != hipSuccess) {
         if (err) *err = CRT_ERR_HIP;
         delete c;
         return nullptr;
     }
     hipMemset(c->d_status, 0, 4);
-    hipMemset(c->d_testctr, 0, 3 * sizeof(unsigned long long));
+    hipMemset(c->d_testctr, 0, 6 * sizeof(unsigned long long));
     c->grid_blocks = trace_grid_blocks(device);
     if (err) *err = CRT_OK;
     return c;
@@ -553,7 +553,7 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
     if (rc) return rc;
     c->h_ctr.assign((size_t)spp * kCtrStride, 0);
     HIPCHECK(c, hipMemsetAsync(c->d_ctr, 0, (size_t)spp * kCtrStride * 4, c->stream));
-    if (c->counting) HIPCHECK(c, hipMemsetAsync(c->d_testctr, 0, 3 * sizeof(unsigned long long), c->stream));
+    if (c->counting) HIPCHECK(c, hipMemsetAsync(c->d_testctr, 0, 6 * sizeof(unsigned long long), c->stream));
     if (c->capture) {
         HIPCHECK(c, hipMemsetD32Async((hipDeviceptr_t)c->cap_ids, -9, (size_t)p->bounces * npix, c->stream));
         HIPCHECK(c, hipMemsetD32Async((hipDeviceptr_t)c->cap_ts, 0, (size_t)p->bounces * npix, c->stream));
@@ -590,7 +590,7 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
             if (c->lights.n > 0) {
                 TraceArgs ts = ta;
                 ts.rayO = c->shO; ts.rayD = c->shD; ts.count = ctr + 16 + b; ts.next = ctr + 48 + b;
-                ts.hitSlot = nullptr; ts.hitT = nullptr; ts.shflag = c->shflag;
+                ts.hitSlot = nullptr; ts.hitT = nullptr; ts.shflag = c->shflag; ts.counters = c->d_testctr + 3;
                 launch_trace(ts, c->lights, TRACE_SHADOW, c->counting, c->grid_blocks, c->stream);
                 mark(c, EV_TRACE_S);
             }
@@ -620,13 +620,14 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
         for (int b = 1; b < p->bounces; b++) st.rays_reflect += h[b];
         for (int b = 0; b < p->bounces; b++) st.rays_shadow += h[16 + b];
     }
-    st.ms_trace = st.ms_shade = st.ms_other = st.ms_trace_nearest = 0; st.launches_trace_nearest = 0;
+    st.ms_trace = st.ms_shade = st.ms_other = st.ms_trace_nearest = st.ms_trace_shadow = 0;
+    st.launches_trace_nearest = st.launches_trace_shadow = 0;
     for (size_t i = 1; i < c->evlog.size(); i++) {
         float ms = 0;
         hipEventElapsedTime(&ms, c->evpool[c->evlog[i - 1].second], c->evpool[c->evlog[i].second]);
         switch (c->evlog[i].first) {
             case EV_TRACE_N: st.ms_trace += ms; st.ms_trace_nearest += ms; st.launches_trace_nearest++; break;
-            case EV_TRACE_S: st.ms_trace += ms; break;
+            case EV_TRACE_S: st.ms_trace += ms; st.ms_trace_shadow += ms; st.launches_trace_shadow++; break;
             case EV_SHADE: case EV_RESOLVE: st.ms_shade += ms; break;
             default: st.ms_other += ms;
         }
@@ -635,9 +636,10 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
     hipEventElapsedTime(&tot, c->evpool[c->evlog.front().second], c->evpool[c->evlog.back().second]);
     st.ms_total = tot;
     if (c->counting) {
-        unsigned long long t[3];
+        unsigned long long t[6];
         HIPCHECK(c, hipMemcpy(t, c->d_testctr, sizeof t, hipMemcpyDeviceToHost));
         st.box_tests = t[0]; st.tri_tests = t[1]; st.sph_tests = t[2];
+        st.box_tests_shadow = t[3]; st.tri_tests_shadow = t[4]; st.sph_tests_shadow = t[5];
     }
     c->last_w = p->width; c->last_h = p->height; c->last_bounces = p->bounces;
     return CRT_OK;
@@ -693,7 +695,7 @@ static int trace_hook(crt_ctx* c, const float* org_dir, int n, int32_t* prim_out
         ta.sv = view_of(c); ta.rayO = d_o; ta.rayD = d_d; ta.count = d_cnt; ta.next = d_cnt + 1;
         ta.hitSlot = d_slot; ta.hitT = d_t; ta.shflag = d_flag; ta.scene_abs = c->scene_abs;
         ta.ovf = c->d_ovf; ta.ovf_depth = c->ovf_depth; ta.counters = c->d_testctr; ta.status = c->d_status;
-        if (c->counting) TH(hipMemsetAsync(c->d_testctr, 0, 3 * sizeof(unsigned long long), c->stream));
+        if (c->counting) TH(hipMemsetAsync(c->d_testctr, 0, 6 * sizeof(unsigned long long), c->stream));
         LightsParam dummy{}; dummy.n = 1;          /* light 0 directional: the Ray.cu:650-656 predicate */
         launch_trace(ta, dummy, shadow_out ? TRACE_SHADOW : TRACE_NEAREST, c->counting, c->grid_blocks, c->stream);
         TH(hipGetLastError());

@@ -1,0 +1,149 @@
+"""Tile sharding of one frame over the GPUs of a node.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" for the CPU
+rehearsal in tests).  Pixels are independent, so the only exchanges are
+  1. broadcast of the packed scene + BVH blob from rank 0 after a build, and
+  2. gather of each rank's tile pixels (BGR8, tile-major) to rank 0, which scatters them into
+     the bottom-up frame.
+There is no reduction anywhere.  torch is used for the device buffers and the collectives only.
+
+The tile -> rank map and the tile-major packing are defined by the C ABI (crt_tile_owner,
+crt_tiles_owned, crt_tiles_pack/unpack); `pack_tiles_host` / `unpack_tiles_host` restate the same
+byte layout on numpy arrays for ranks that hold their pixels on the host (the gloo tests).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import api
+
+
+def packed_nbytes(params, rank=None):
+    """Bytes of the tile-major buffer of `rank` (tiles are stored whole, clipped pixels left unset)."""
+    p = api.Params.from_buffer_copy(params)
+    if rank is not None:
+        p.rank = rank
+    ids, _ = api.tiles_owned(p)
+    return len(ids) * p.tile_w * p.tile_h * 3
+
+
+def _tile_pixel_index(params, rank):
+    p = api.Params.from_buffer_copy(params)
+    p.rank = rank
+    ids, _ = api.tiles_owned(p)
+    tw, th = p.tile_w, p.tile_h
+    tiles_x = (p.width + tw - 1) // tw
+    r = np.arange(tw * th)
+    px = (ids[:, None] % tiles_x) * tw + (r % tw)[None, :]
+    py = (ids[:, None] // tiles_x) * th + (r // tw)[None, :]
+    valid = (px < p.width) & (py < p.height)
+    return (py * p.width + px).ravel(), valid.ravel()
+
+
+def pack_tiles_host(params, rank, frame_bgr):
+    """frame (h, w, 3) uint8 -> tile-major bytes of `rank`, same layout as crt_tiles_pack."""
+    pix, valid = _tile_pixel_index(params, rank)
+    flat = np.ascontiguousarray(frame_bgr, np.uint8).reshape(-1, 3)
+    out = np.zeros((len(pix), 3), np.uint8)
+    out[valid] = flat[pix[valid]]
+    return out.ravel()
+
+
+def unpack_tiles_host(params, src_rank, packed, frame_bgr):
+    """inverse of pack_tiles_host: scatter `src_rank`'s tiles into frame (h, w, 3) in place."""
+    pix, valid = _tile_pixel_index(params, src_rank)
+    flat = frame_bgr.reshape(-1, 3)
+    flat[pix[valid]] = np.asarray(packed, np.uint8).reshape(-1, 3)[valid]
+    return frame_bgr
+
+
+def gather_frame_host(dist, params, local_packed, rank, world):
+    """Gather every rank's tile bytes to rank 0 (any backend, host tensors) and assemble the frame."""
+    import torch
+    sizes = [packed_nbytes(params, r) for r in range(world)]
+    mx = max(sizes)
+    buf = torch.zeros(mx, dtype=torch.uint8)
+    buf[: len(local_packed)] = torch.from_numpy(np.ascontiguousarray(local_packed))
+    out = [torch.zeros(mx, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, out, dst=0)
+    if rank != 0:
+        return None
+    frame = np.zeros((params.height, params.width, 3), np.uint8)
+    for r in range(world):
+        unpack_tiles_host(params, r, out[r][: sizes[r]].numpy(), frame)
+    return frame
+
+
+class ShardedRenderer:
+    """Device path: one crt Context per rank, scene broadcast once, per-frame tile gather over RCCL."""
+
+    def __init__(self, dist, torch, rank, world, local_rank):
+        self.dist, self.torch, self.rank, self.world = dist, torch, rank, world
+        self.dev = torch.device("cuda", local_rank)
+        self.ctx = api.Context(local_rank)
+        self._hip = C.CDLL("libamdhip64.so")
+        self._hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self._hip.hipMemcpy.restype = C.c_int
+        self.frame = None
+        self.packed = None
+        self.gathered = None
+        self.sizes = None
+
+    def broadcast_scene(self, prims=None, lights=None, mode=0):
+        """Rank 0 builds; everyone ends with the same packed scene + BVH resident in its HBM."""
+        torch, dist = self.torch, self.dist
+        if self.rank == 0:
+            self.ctx.set_scene(prims)
+            self.ctx.build(mode)
+            ptr, nbytes = self.ctx.blob()
+        else:
+            ptr, nbytes = 0, 0
+        n = torch.tensor([nbytes], dtype=torch.int64, device=self.dev)
+        dist.broadcast(n, 0)
+        nbytes = int(n.item())
+        blob = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+        if self.rank == 0:
+            rc = self._hip.hipMemcpy(blob.data_ptr(), ptr, nbytes, 3)   # hipMemcpyDeviceToDevice
+            if rc != 0:
+                raise RuntimeError(f"hipMemcpy of the scene blob failed: {rc}")
+        dist.broadcast(blob, 0)
+        torch.cuda.synchronize(self.dev)
+        if self.rank != 0:
+            self.ctx.import_blob(blob.data_ptr(), nbytes)
+        lt = torch.from_numpy(np.frombuffer(np.ascontiguousarray(lights, api.LIGHT_DTYPE).tobytes(), np.uint8).copy()) \
+            if self.rank == 0 else None
+        ln = torch.tensor([0 if lt is None else lt.numel()], dtype=torch.int64, device=self.dev)
+        dist.broadcast(ln, 0)
+        lb = lt.to(self.dev) if self.rank == 0 else torch.empty(int(ln.item()), dtype=torch.uint8, device=self.dev)
+        dist.broadcast(lb, 0)
+        self.ctx.set_lights(np.frombuffer(lb.cpu().numpy().tobytes(), api.LIGHT_DTYPE))
+        return nbytes
+
+    def _ensure(self, params):
+        torch = self.torch
+        npix = params.width * params.height
+        if self.frame is None or self.frame.numel() != npix * 3:
+            self.frame = torch.zeros(npix * 3, dtype=torch.uint8, device=self.dev)
+        sizes = [packed_nbytes(params, r) for r in range(self.world)]
+        if self.sizes != sizes:
+            self.sizes = sizes
+            mx = max(sizes)
+            self.packed = torch.zeros(mx, dtype=torch.uint8, device=self.dev)
+            self.gathered = [torch.zeros(mx, dtype=torch.uint8, device=self.dev) for _ in range(self.world)] \
+                if self.rank == 0 else None
+
+    def render(self, cam, target, params):
+        """Render this rank's tiles, gather to rank 0.  Returns the device frame tensor on rank 0."""
+        params.rank, params.nranks = self.rank, self.world
+        self._ensure(params)
+        self.ctx.render_device(cam, target, params, self.frame.data_ptr())
+        if self.world == 1:
+            return self.frame
+        self.ctx.tiles_pack(params, self.frame.data_ptr(), self.packed.data_ptr())
+        self.dist.gather(self.packed, self.gathered, dst=0)
+        if self.rank == 0:
+            self.torch.cuda.synchronize(self.dev)
+            for r in range(1, self.world):
+                self.ctx.tiles_unpack(params, r, self.gathered[r].data_ptr(), self.frame.data_ptr())
+            return self.frame
+        return None

@@ -76,11 +76,15 @@ typedef struct crt_params {
 
 typedef struct crt_stats {
     uint64_t rays_primary, rays_shadow, rays_reflect;   /* traversals issued by the last crt_render* call */
-    uint64_t box_tests, tri_tests, sph_tests;            /* filled only when crt_set_counting(ctx,1) */
+    /* filled only when crt_set_counting(ctx,1): AABB / triangle / sphere tests of the nearest-hit
+     * launches and of the shadow launches (the counts behind the algorithmic-bytes figure) */
+    uint64_t box_tests, tri_tests, sph_tests;
+    uint64_t box_tests_shadow, tri_tests_shadow, sph_tests_shadow;
     double ms_total;         /* device time of the last crt_render* call (HIP events on the context's stream) */
     double ms_trace, ms_shade, ms_other;
     double ms_trace_nearest; /* summed duration of the nearest-hit traversal launches (dominant kernel) */
-    int32_t launches_trace_nearest;
+    double ms_trace_shadow;
+    int32_t launches_trace_nearest, launches_trace_shadow;
     int32_t nodes, prims, depth, leaves;
     double ms_build_host, ms_refit;
     uint64_t scene_bytes;    /* packed scene + BVH bytes resident in HBM */
