@@ -61,7 +61,7 @@ struct crt_ctx {
     uint8_t* shflag = nullptr;
     uint8_t* d_bgr = nullptr; size_t bgr_cap = 0;
     int32_t* cap_ids = nullptr; float* cap_ts = nullptr; size_t cap_planes = 0; size_t cap_npix = 0;
-    uint32_t* d_tiles = nullptr; size_t tiles_cap = 0; std::vector<uint32_t> tiles; crt_params tiles_for{};
+    uint32_t* d_tiles = nullptr; size_t tiles_cap = 0; std::vector<uint32_t> tiles; crt_params tiles_for{}; int64_t owned_pixels = 0;
     uint32_t* d_ctr = nullptr; size_t ctr_cap = 0; std::vector<uint32_t> h_ctr;
     uint32_t* d_status = nullptr;
     unsigned long long* d_testctr = nullptr;
@@ -208,7 +208,7 @@ int ensure_tiles(crt_ctx* c, const crt_params* p) {
     if (rc) return rc;
     HIPCHECK(c, hipMemcpyAsync(c->d_tiles, c->tiles.data(), nt * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
-    c->tiles_for = *p;
+    c->tiles_for = *p; c->owned_pixels = np;
     return CRT_OK;
 }
 
@@ -616,7 +616,8 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
     st.rays_primary = st.rays_shadow = st.rays_reflect = 0;
     for (int s = 0; s < spp; s++) {
         const uint32_t* h = &c->h_ctr[(size_t)s * kCtrStride];
-        st.rays_primary += h[0];
+        (void)h[0];                       /* queue length including holes of clipped tiles */
+        st.rays_primary += (uint64_t)c->owned_pixels;
         for (int b = 1; b < p->bounces; b++) st.rays_reflect += h[b];
         for (int b = 0; b < p->bounces; b++) st.rays_shadow += h[16 + b];
     }

@@ -74,6 +74,14 @@ CRT_DEV bool sphere_test(const GeomRec& g, const vec3& o, const vec3& d, float& 
 
 /* ------------------------------------------------------------------------------------------
  * k_trace
+ *
+ * Every active lane always holds one work item: an internal node (`cur`) or a pending range of
+ * primitives of a leaf ([lp, lend)).  Each iteration the WAVE votes: if more lanes hold a node,
+ * the wave runs one node step (those lanes test 4 child boxes), otherwise one primitive step
+ * (those lanes test one primitive).  The branch is wave-uniform, so the two bodies never
+ * serialise against each other inside one iteration; the minority lanes keep their item.
+ * (First version ran "if node ... else leaf-loop" per lane: VALU lane utilisation was 27 %,
+ * profiles/r01a_first_path.md.)
  * ------------------------------------------------------------------------------------------ */
 #define CSWAP(ta, la, tb, lb)                                   \
     {                                                           \
@@ -99,10 +107,33 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs A, LightsParam 
     float tbest = 0;
     int best = -1;
     uint32_t cur = 0, ray = 0;
+    uint32_t lp = 0, lend = 0;      /* pending primitives of the current leaf */
     int sp = 0;
     int found = 0;          /* SHADOW: a hit with t > 1e-9 exists */
     int lightj = 0;
     unsigned long long nbox = 0, ntri = 0, nsph = 0;
+
+    /* take the next item off the stack, or report that the ray is finished */
+#define POP_ITEM(FINISH)                                                                 \
+    {                                                                                    \
+        if (sp == 0) FINISH = true;                                                      \
+        else {                                                                           \
+            sp--;                                                                        \
+            uint32_t l_;                                                                 \
+            if (sp < kStackDepth) l_ = s_stack[sp][tid];                                 \
+            else if (sp - kStackDepth < A.ovf_depth) l_ = ovf[sp - kStackDepth];         \
+            else { l_ = 0; FINISH = true; } /* dropped entry: status word already set */ \
+            if (l_ & kLeafFlag) { lp = l_ & kLeafStartMask; lend = lp + ((l_ >> kLeafCountShift) & 63u) + 1u; } \
+            else cur = l_;                                                               \
+        }                                                                                \
+    }
+#define PUSH_ITEM(L)                                                                     \
+    {                                                                                    \
+        if (sp < kStackDepth) s_stack[sp][tid] = (L);                                    \
+        else if (sp - kStackDepth < A.ovf_depth) ovf[sp - kStackDepth] = (L);            \
+        else atomicOr(A.status, 1u);                                                     \
+        sp++;                                                                            \
+    }
 
     for (;;) {
         /* ---- refill idle lanes from the queue ---- */
@@ -117,37 +148,46 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs A, LightsParam 
                     const uint32_t idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                     if (idx < total) {
                         const float4 ro = A.rayO[idx], rd = A.rayD[idx];
-                        ray = idx;
-                        o = vec3(ro.x, ro.y, ro.z); d = vec3(rd.x, rd.y, rd.z);
-                        if (MODE == TRACE_SHADOW) { ray = __float_as_uint(ro.w); lightj = (int)__float_as_uint(rd.w); }
-                        /* clamped reciprocal: a zero component (the centre pixel column has
-                         * direction.x == 0 exactly) becomes +-1e20 instead of inf, so 0*inf never appears */
-                        float rx = 1.0f / d.x, ry = 1.0f / d.y, rz = 1.0f / d.z;
-                        if (!(fabsf(d.x) > 1e-20f)) rx = copysignf(1e20f, d.x);
-                        if (!(fabsf(d.y) > 1e-20f)) ry = copysignf(1e20f, d.y);
-                        if (!(fabsf(d.z) > 1e-20f)) rz = copysignf(1e20f, d.z);
-                        ix = rx; iy = ry; iz = rz;
-                        /* boxes are stored exact; the test pads them: lo' = lo - pad, hi' = hi + pad */
-                        const float px = 1e-3f + 1e-6f * (fabsf(o.x) + A.scene_abs);
-                        const float py = 1e-3f + 1e-6f * (fabsf(o.y) + A.scene_abs);
-                        const float pz = 1e-3f + 1e-6f * (fabsf(o.z) + A.scene_abs);
-                        ax = (o.x + px) * ix; bx = (o.x - px) * ix;
-                        ay = (o.y + py) * iy; by = (o.y - py) * iy;
-                        az = (o.z + pz) * iz; bz = (o.z - pz) * iz;
-                        tbest = 1000000000.0f; best = -1; cur = 0; sp = 0; found = 0;
-                        active = true;
+                        if (MODE == TRACE_NEAREST && __float_as_uint(rd.w) == 0xffffffffu) {
+                            A.hitSlot[idx] = -3;            /* hole in the primary queue: pixel outside the frame */
+                            A.hitT[idx] = 0.f;
+                        } else {
+                            ray = idx;
+                            o = vec3(ro.x, ro.y, ro.z); d = vec3(rd.x, rd.y, rd.z);
+                            if (MODE == TRACE_SHADOW) { ray = __float_as_uint(ro.w); lightj = (int)__float_as_uint(rd.w); }
+                            /* clamped reciprocal: a zero component (the centre pixel column has
+                             * direction.x == 0 exactly) becomes +-1e20 instead of inf, so 0*inf never appears */
+                            float rx = 1.0f / d.x, ry = 1.0f / d.y, rz = 1.0f / d.z;
+                            if (!(fabsf(d.x) > 1e-20f)) rx = copysignf(1e20f, d.x);
+                            if (!(fabsf(d.y) > 1e-20f)) ry = copysignf(1e20f, d.y);
+                            if (!(fabsf(d.z) > 1e-20f)) rz = copysignf(1e20f, d.z);
+                            ix = rx; iy = ry; iz = rz;
+                            /* boxes are stored exact; the test pads them: lo' = lo - pad, hi' = hi + pad */
+                            const float px = 1e-3f + 1e-6f * (fabsf(o.x) + A.scene_abs);
+                            const float py = 1e-3f + 1e-6f * (fabsf(o.y) + A.scene_abs);
+                            const float pz = 1e-3f + 1e-6f * (fabsf(o.z) + A.scene_abs);
+                            ax = (o.x + px) * ix; bx = (o.x - px) * ix;
+                            ay = (o.y + py) * iy; by = (o.y - py) * iy;
+                            az = (o.z + pz) * iz; bz = (o.z - pz) * iz;
+                            tbest = 1000000000.0f; best = -1; cur = 0; sp = 0; found = 0; lp = lend = 0;
+                            active = true;
+                        }
                     }
                 }
                 if (base + (uint32_t)nidle >= total) exhausted = true;
             }
         }
-        if (__ballot(active) == 0ull) break;
+        if (__ballot(active) == 0ull) { if (exhausted) break; else continue; }
 
         /* ---- traverse until enough lanes idle to be worth a refill ---- */
         do {
-            if (active) {
-                bool finish = false;
-                if (!(cur & kLeafFlag)) {
+            const bool want_prim = active && (lp < lend);
+            const bool want_node = active && !want_prim;
+            const int n_node = __popcll(__ballot(want_node));
+            const int n_prim = __popcll(__ballot(want_prim));
+            bool finish = false;
+            if (n_node >= n_prim) {
+                if (want_node) {
                     const float4* np = reinterpret_cast<const float4*>(A.sv.nodes + cur);
                     const float4 lox = np[0], loy = np[1], loz = np[2], hix = np[3], hiy = np[4], hiz = np[5];
                     const uint4 ch = reinterpret_cast<const uint4*>(np)[6];
@@ -173,30 +213,24 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs A, LightsParam 
                     CSWAP(tn0, c0, tn2, c2)
                     CSWAP(tn1, c1, tn3, c3)
                     CSWAP(tn1, c1, tn2, c2)
-                    /* nearest child continues in `cur`; the others go on the stack far-first */
-#define PUSH(L)                                                                          \
-    {                                                                                    \
-        if (sp < kStackDepth) s_stack[sp][tid] = (L);                                    \
-        else if (sp - kStackDepth < A.ovf_depth) ovf[sp - kStackDepth] = (L);            \
-        else atomicOr(A.status, 1u);                                                     \
-        sp++;                                                                            \
-    }
-                    if (tn3 < INFINITY) PUSH(c3)
-                    if (tn2 < INFINITY) PUSH(c2)
-                    if (tn1 < INFINITY) PUSH(c1)
-#undef PUSH
-                    if (tn0 < INFINITY) cur = c0;
-                    else cur = kChildEmpty;
-                } else {
-                    const uint32_t start = cur & kLeafStartMask;
-                    const uint32_t cnt = ((cur >> kLeafCountShift) & 63u) + 1u;
-                    for (uint32_t p = start; p < start + cnt; p++) {
-                        const GeomRec g = load_geom(A.sv.geom, p);
-                        float t, tsm;
-                        bool hit;
-                        if (is_sphere(g)) { if (COUNT) nsph++; hit = sphere_test(g, o, d, t, tsm); }
-                        else { if (COUNT) ntri++; hit = tri_test(g, o, d, tbest, t); }
-                        if (!hit) continue;
+                    /* nearest child becomes the next item; the others go on the stack far-first */
+                    if (tn3 < INFINITY) PUSH_ITEM(c3)
+                    if (tn2 < INFINITY) PUSH_ITEM(c2)
+                    if (tn1 < INFINITY) PUSH_ITEM(c1)
+                    if (tn0 < INFINITY) {
+                        if (c0 & kLeafFlag) { lp = c0 & kLeafStartMask; lend = lp + ((c0 >> kLeafCountShift) & 63u) + 1u; }
+                        else cur = c0;
+                    } else POP_ITEM(finish)
+                }
+            } else {
+                if (want_prim) {
+                    const uint32_t p = lp++;
+                    const GeomRec g = load_geom(A.sv.geom, p);
+                    float t = 0.f, tsm;
+                    bool hit;
+                    if (is_sphere(g)) { if (COUNT) nsph++; hit = sphere_test(g, o, d, t, tsm); }
+                    else { if (COUNT) ntri++; hit = tri_test(g, o, d, tbest, t); }
+                    if (hit) {
                         if (MODE == TRACE_NEAREST) {
                             /* strict '<' as Ray.cu:199,216; equal t resolves to the primitive the
                              * reference would have met first (lower rank in its leaf order) */
@@ -205,47 +239,40 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs A, LightsParam 
                             if (LP.l[lightj].point) {           /* nearest t decides, Ray.cu:621-629 */
                                 if (t < tbest) { tbest = t; best = (int)p; }
                             } else {                              /* Ray.cu:650-656: hit exists and min t > 1e-9 */
-                                if (!(t > 0.000000001f)) { found = 0; best = -2; finish = true; break; }
-                                found = 1; if (tbest > 0.000000001f) tbest = 0.000000001f;
+                                if (!(t > 0.000000001f)) { found = 0; finish = true; }
+                                else { found = 1; if (tbest > 0.000000001f) tbest = 0.000000001f; }
                             }
                         }
                     }
-                    cur = kChildEmpty;
+                    if (lp == lend && !finish) POP_ITEM(finish)
                 }
-                if (cur == kChildEmpty && !finish) {
-                    if (sp == 0) finish = true;
-                    else {
-                        sp--;
-                        if (sp < kStackDepth) cur = s_stack[sp][tid];
-                        else if (sp - kStackDepth < A.ovf_depth) cur = ovf[sp - kStackDepth];
-                        else finish = true;          /* entry was dropped: status word already set, result invalid */
-                    }
+            }
+            if (finish) {
+                if (MODE == TRACE_NEAREST) {
+                    A.hitSlot[ray] = best;
+                    A.hitT[ray] = tbest;
+                } else {
+                    bool shadowed;
+                    if (LP.l[lightj].point) {
+                        shadowed = false;
+                        if (best >= 0) {
+                            const vec3 lpos(LP.l[lightj].position);
+                            const vec3 ipoint = o + tbest * d;
+                            const float ex = o.x - lpos.x, ey = o.y - lpos.y, ez = o.z - lpos.z;
+                            const float dtoLight = sqrtf(ex * ex + ey * ey + ez * ez);
+                            const float fx = ipoint.x - o.x, fy = ipoint.y - o.y, fz = ipoint.z - o.z;
+                            const float dtoLightIntersection = sqrtf(fx * fx + fy * fy + fz * fz);
+                            shadowed = dtoLight > dtoLightIntersection;
+                        }
+                    } else shadowed = (found != 0);
+                    if (shadowed) A.shflag[ray] = 1;
                 }
-                if (finish) {
-                    if (MODE == TRACE_NEAREST) {
-                        A.hitSlot[ray] = best;
-                        A.hitT[ray] = tbest;
-                    } else {
-                        bool shadowed;
-                        if (LP.l[lightj].point) {
-                            shadowed = false;
-                            if (best >= 0) {
-                                const vec3 lpos(LP.l[lightj].position);
-                                const vec3 ipoint = o + tbest * d;
-                                const float ex = o.x - lpos.x, ey = o.y - lpos.y, ez = o.z - lpos.z;
-                                const float dtoLight = sqrtf(ex * ex + ey * ey + ez * ez);
-                                const float fx = ipoint.x - o.x, fy = ipoint.y - o.y, fz = ipoint.z - o.z;
-                                const float dtoLightIntersection = sqrtf(fx * fx + fy * fy + fz * fz);
-                                shadowed = dtoLight > dtoLightIntersection;
-                            }
-                        } else shadowed = (found != 0);
-                        if (shadowed) A.shflag[ray] = 1;
-                    }
-                    active = false;
-                }
+                active = false; lp = lend = 0;
             }
         } while (exhausted ? (__ballot(active) != 0ull) : (__popcll(__ballot(active)) > 64 - kRefillMinIdle));
     }
+#undef POP_ITEM
+#undef PUSH_ITEM
     if (COUNT) {
         atomicAdd(&A.counters[0], nbox);
         atomicAdd(&A.counters[1], ntri);
@@ -256,8 +283,13 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs A, LightsParam 
 int trace_grid_blocks(int device) {
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device) != hipSuccess) return 1024;
-    /* 32 KB of LDS stack per block -> 5 blocks of 4 waves per CU (160 KB LDS) */
-    return p.multiProcessorCount * 5;
+    /* persistent grid = what is resident at once: limited by the 32 KB LDS stack per block (5 blocks
+     * per CU) and by the kernel's VGPR allocation; ask the runtime for the tighter of the two */
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<TRACE_NEAREST, false>, kTraceBlock, 0) != hipSuccess || per_cu < 1)
+        per_cu = 4;
+    if (per_cu > 5) per_cu = 5;
+    return p.multiProcessorCount * per_cu;
 }
 
 void launch_trace(const TraceArgs& a, const LightsParam& lights, int mode, bool counting, int blocks, hipStream_t s) {
@@ -293,21 +325,22 @@ __global__ __launch_bounds__(256) void k_gen_primary(FrameParams P, FrameBuffers
     const uint32_t per_tile = (uint32_t)(P.tile_w * P.tile_h);
     const uint32_t total = (uint32_t)P.ntiles_owned * per_tile;
     const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t rounded = (total + 63u) & ~63u;
-    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < rounded; q += stride) {
-        bool valid = q < total;
-        int px = 0, py = 0;
-        if (valid) {
-            const uint32_t tile = B.tile_ids[q / per_tile];
-            const uint32_t r = q % per_tile;
-            const uint32_t blk = r >> 6, l = r & 63u;
-            const uint32_t bpr = (uint32_t)P.tile_w >> 3;
-            px = (int)((tile % (uint32_t)P.tiles_x) * (uint32_t)P.tile_w + (blk % bpr) * 8u + (l & 7u));
-            py = (int)((tile / (uint32_t)P.tiles_x) * (uint32_t)P.tile_h + (blk / bpr) * 8u + (l >> 3));
-            valid = px < P.width && py < P.height;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count = total;
+    /* queue slot == path index: no compaction, no atomics.  Pixels of a clipped tile that fall
+     * outside the frame leave a flagged hole that k_trace and k_shade skip. */
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
+        const uint32_t tile = B.tile_ids[q / per_tile];
+        const uint32_t r = q % per_tile;
+        const uint32_t blk = r >> 6, l = r & 63u;
+        const uint32_t bpr = (uint32_t)P.tile_w >> 3;
+        const int px = (int)((tile % (uint32_t)P.tiles_x) * (uint32_t)P.tile_w + (blk % bpr) * 8u + (l & 7u));
+        const int py = (int)((tile / (uint32_t)P.tiles_x) * (uint32_t)P.tile_h + (blk / bpr) * 8u + (l >> 3));
+        if (!(px < P.width && py < P.height)) {
+            B.rayO[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            B.rayD[q] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffffffu));
+            B.pix[q] = 0xffffffffu;
+            continue;
         }
-        const uint32_t k = queue_slot(valid, count);
-        if (!valid) continue;
         const vec3 L(P.L), u(P.u), v(P.v), cam(P.cam);
         vec3 pix;
         if (P.spp_n <= 1) {
@@ -319,10 +352,9 @@ __global__ __launch_bounds__(256) void k_gen_primary(FrameParams P, FrameBuffers
         }
         const float xoffset = 0, yoffset = 0;
         const vec3 sample = normalize(vec3(pix.x + xoffset, pix.y + yoffset, pix.z) - cam);
-        B.rayO[k] = make_float4(cam.x, cam.y, cam.z, 0.f);
-        B.rayD[k] = make_float4(sample.x, sample.y, sample.z, 0.f);
-        B.pix[k] = (uint32_t)(py * P.width + px);
-        B.coef[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        B.rayO[q] = make_float4(cam.x, cam.y, cam.z, 0.f);
+        B.rayD[q] = make_float4(sample.x, sample.y, sample.z, 0.f);
+        B.pix[q] = (uint32_t)(py * P.width + px);
     }
 }
 
@@ -351,12 +383,18 @@ __constant__ WallDef c_walls[6] = {
 
 __global__ __launch_bounds__(256) void k_shade(FrameParams P, FrameBuffers B, SceneView sv, LightsParam LP,
                                                 const uint32_t* count, uint32_t* next_count, uint32_t* shadow_count) {
+    /* queue appends are reserved once per BLOCK iteration (LDS partial sums + one atomic per
+     * queue): per-wave atomics on the two counters made this kernel atomic-bound */
+    __shared__ uint32_t s_cnt[2][4];
+    __shared__ uint32_t s_base[2];
     const uint32_t total = *count;
     const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t rounded = (total + 63u) & ~63u;
+    const uint32_t rounded = (total + 255u) & ~255u;
     const int raytype = P.bounce > 0 ? 1 : 0;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += stride) {
-        const bool valid = i < total;
+        const bool valid = i < total && B.hitSlot[i] != -3;      /* -3: hole left by a clipped tile */
+        if (i < total && !valid) B.rc[i] = make_float4(0.f, 0.f, 0.f, 0.f);   /* k_resolve skips w == 0 */
         bool dead = !valid;
         vec3 o, d, cin, P_, N, incident, rc, newcoef, diffuse, specular;
         float shininess = 0.f;
@@ -448,6 +486,30 @@ __global__ __launch_bounds__(256) void k_shade(FrameParams P, FrameBuffers B, Sc
             B.rc[i] = make_float4(rc.x, rc.y, rc.z, dead ? 0.f : 1.f);
         }
 
+        /* ---- reserve queue space: count this block's shadow and reflection rays ---- */
+        const bool emit = !dead && (P.bounce + 1 < P.bounces) && (newcoef.x != 0.f || newcoef.y != 0.f || newcoef.z != 0.f);
+        uint32_t wave_sh = 0;
+        for (int j = 0; j < LP.n; j++) {
+            bool want = false;
+            if (!dead) {
+                if (LP.l[j].point) want = true;
+                else want = !((double)dot(normalize(vec3(LP.l[j].direction)), N) > -0.00001);
+            }
+            wave_sh += (uint32_t)__popcll(__ballot(want));
+        }
+        const unsigned long long emit_mask = __ballot(emit);
+        if (lane == 0) { s_cnt[0][wv] = wave_sh; s_cnt[1][wv] = (uint32_t)__popcll(emit_mask); }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t tsh = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
+            const uint32_t trf = s_cnt[1][0] + s_cnt[1][1] + s_cnt[1][2] + s_cnt[1][3];
+            s_base[0] = tsh ? atomicAdd(shadow_count, tsh) : 0u;
+            s_base[1] = trf ? atomicAdd(next_count, trf) : 0u;
+        }
+        __syncthreads();
+        uint32_t sh_run = s_base[0], rf_base = s_base[1];
+        for (int w = 0; w < wv; w++) { sh_run += s_cnt[0][w]; rf_base += s_cnt[1][w]; }
+
         /* ---- Shade's light loop, Ray.cu:560-659 ---- */
         vec3 direction, intersection = P_;
         if (!dead) direction = normalize(incident);
@@ -484,23 +546,25 @@ __global__ __launch_bounds__(256) void k_shade(FrameParams P, FrameBuffers B, Sc
                 B.contrib[(size_t)j * B.cap + i] = make_float4(X.x, X.y, X.z, distance);
                 B.shflag[(size_t)j * B.cap + i] = flag;
             }
-            const uint32_t ks = queue_slot(want, shadow_count);
+            const unsigned long long wm = __ballot(want);
             if (want) {
+                const uint32_t ks = sh_run + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull));
                 B.shO[ks] = make_float4(sorg.x, sorg.y, sorg.z, __uint_as_float((uint32_t)((size_t)j * B.cap + i)));
                 B.shD[ks] = make_float4(toLight.x, toLight.y, toLight.z, __uint_as_float((uint32_t)j));
             }
+            sh_run += (uint32_t)__popcll(wm);
         }
 
         /* ---- reflected ray, Ray.cu:494-496 / 519-520; paths whose coefficient is zero end here ---- */
-        const bool emit = !dead && (P.bounce + 1 < P.bounces) && (newcoef.x != 0.f || newcoef.y != 0.f || newcoef.z != 0.f);
-        const uint32_t kn = queue_slot(emit, next_count);
         if (emit) {
+            const uint32_t kn = rf_base + (uint32_t)__popcll(emit_mask & ((1ull << lane) - 1ull));
             const vec3 rdir = normalize(reflect(d, N));
             B.nrayO[kn] = make_float4(P_.x, P_.y, P_.z, 0.f);
             B.nrayD[kn] = make_float4(rdir.x, rdir.y, rdir.z, 0.f);
             B.ncoef[kn] = make_float4(newcoef.x, newcoef.y, newcoef.z, 0.f);
             B.npix[kn] = pix;
         }
+        __syncthreads();     /* s_cnt / s_base are reused by the next iteration */
     }
 }
 
@@ -525,6 +589,7 @@ __global__ __launch_bounds__(256) void k_resolve(FrameBuffers B, LightsParam LP,
             color += distance * vec3(LP.l[j].color) * vec3(c.x, c.y, c.z);
         }
         const uint32_t pix = B.pix[i];
+        if (pix == 0xffffffffu) continue;
         float4 a = B.accum[pix];
         vec3 acc(a.x, a.y, a.z);
         acc += vec3(rc4.x, rc4.y, rc4.z) * color;

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile.sh output directory into one JSON/markdown summary under profiles/.
+
+usage: tools/pmc_summary.py gpurun_out/prof_<tag> profiles/<name>
+Per kernel: calls, average duration (kernel trace) and the per-launch average of every PMC counter
+collected.  HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md "HBM": FETCH_SIZE and
+WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes for wide
+coalesced streaming reads and is uncalibrated for other widths, so both the raw and the doubled
+figure are reported.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = name.replace("void ", "").replace("crt::", "")
+    return name.split("(")[0]
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    out = {"source": src, "kernels": {}}
+    for f in glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv")):
+        for r in csv.DictReader(open(f)):
+            out["kernels"][short(r["Name"])] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
+                                                 "total_ms": float(r["TotalDurationNs"]) / 1e6, "pct": float(r["Percentage"])}
+    for d in sorted(glob.glob(os.path.join(src, "pmc*"))):
+        if not os.path.isdir(d):
+            continue
+        for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+            acc = defaultdict(lambda: defaultdict(list))
+            meta = {}
+            for r in csv.DictReader(open(f)):
+                k = short(r["Kernel_Name"])
+                acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                meta[k] = {"vgpr": int(r["VGPR_Count"]), "sgpr": int(r["SGPR_Count"]), "lds": int(r["LDS_Block_Size"]),
+                           "scratch": int(r["Scratch_Size"])}
+            for k, cs in acc.items():
+                e = out["kernels"].setdefault(k, {})
+                e.update(meta[k])
+                pm = e.setdefault("pmc_per_launch_avg", {})
+                for c, v in cs.items():
+                    pm[c] = sum(v) / len(v)
+    for k, e in out["kernels"].items():
+        pm = e.get("pmc_per_launch_avg", {})
+        if "FETCH_SIZE" in pm:
+            e["hbm_read_bytes_per_launch_raw"] = pm["FETCH_SIZE"] * 1024
+            e["hbm_read_bytes_per_launch_x2_gfx950"] = pm["FETCH_SIZE"] * 2048
+        if "WRITE_SIZE" in pm:
+            e["hbm_write_bytes_per_launch"] = pm["WRITE_SIZE"] * 1024
+        if "TCC_HIT_sum" in pm and "TCC_MISS_sum" in pm and pm["TCC_HIT_sum"] + pm["TCC_MISS_sum"] > 0:
+            e["l2_hit_rate"] = pm["TCC_HIT_sum"] / (pm["TCC_HIT_sum"] + pm["TCC_MISS_sum"])
+        if "SQ_WAVE_CYCLES" in pm and pm.get("SQ_WAVE_CYCLES", 0) > 0:
+            if "SQ_ACTIVE_INST_VALU" in pm:
+                e["valu_active_frac_of_wave_cycles"] = pm["SQ_ACTIVE_INST_VALU"] * 4 / pm["SQ_WAVE_CYCLES"]
+            if "SQ_WAIT_ANY" in pm:
+                e["wait_any_frac_of_wave_cycles"] = pm["SQ_WAIT_ANY"] * 4 / pm["SQ_WAVE_CYCLES"] if False else pm["SQ_WAIT_ANY"] / pm["SQ_WAVE_CYCLES"]
+        if "SQ_THREAD_CYCLES_VALU" in pm and pm.get("SQ_ACTIVE_INST_VALU", 0) > 0:
+            e["valu_lane_utilisation"] = pm["SQ_THREAD_CYCLES_VALU"] / (pm["SQ_ACTIVE_INST_VALU"] * 64)
+    for name in ("bench_kt.json",):
+        p = os.path.join(src, name)
+        if os.path.exists(p):
+            try:
+                out["bench_line_under_kernel_trace"] = json.loads(open(p).read().strip().splitlines()[-1])
+            except Exception:
+                pass
+    os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
+    json.dump(out, open(dst + ".json", "w"), indent=1, sort_keys=True)
+    with open(dst + ".md", "w") as f:
+        f.write(f"# rocprofv3 summary ({src})\n\n| kernel | calls | avg ms | % | VGPR | LDS | L2 hit | HBM read/launch (raw, x2) | HBM write/launch | VALU lane util |\n|---|---|---|---|---|---|---|---|---|---|\n")
+        for k, e in sorted(out["kernels"].items(), key=lambda kv: -kv[1].get("total_ms", 0)):
+            f.write("| {} | {} | {:.4f} | {:.2f} | {} | {} | {} | {} | {} | {} |\n".format(
+                k, e.get("calls", ""), e.get("avg_ms", 0), e.get("pct", 0), e.get("vgpr", ""), e.get("lds", ""),
+                "{:.3f}".format(e["l2_hit_rate"]) if "l2_hit_rate" in e else "",
+                "{:.1f} MB, {:.1f} MB".format(e["hbm_read_bytes_per_launch_raw"] / 1e6, e["hbm_read_bytes_per_launch_x2_gfx950"] / 1e6) if "hbm_read_bytes_per_launch_raw" in e else "",
+                "{:.1f} MB".format(e["hbm_write_bytes_per_launch"] / 1e6) if "hbm_write_bytes_per_launch" in e else "",
+                "{:.3f}".format(e["valu_lane_utilisation"]) if "valu_lane_utilisation" in e else ""))
+    print("wrote", dst + ".json", dst + ".md")
+
+
+if __name__ == "__main__":
+    main()
