@@ -9,7 +9,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-lib_path = os.path.join(_HERE, "libcrt_amd.so")
+lib_path = os.environ.get("CRT_LIB") or os.path.join(_HERE, "libcrt_amd.so")   # CRT_LIB: A/B builds in experiments
 TEAPOT_OBJ = os.path.join(_ROOT, "tests", "golden", "teapot3.obj")
 
 if not os.path.exists(lib_path):

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <thread>
 #include <functional>
+#include <cstdlib>
 
 namespace crt {
 
@@ -254,10 +255,22 @@ struct PrimRef { AABB box; float c[3]; int idx; };
 constexpr int kBins = 16;
 constexpr int kWideLeaf = 4;
 
+/* SAH termination: a range of n <= max_leaf primitives becomes a leaf when n * 1 (cost of n
+ * primitive tests) <= node_cost + (A_L n_L + A_R n_R) / A.  Tunables for experiments:
+ * CRT_SAH_NODE_COST (default below), CRT_MAX_LEAF (1..4). */
+struct WideTuning { float node_cost; int max_leaf; };
+WideTuning wide_tuning() {
+    WideTuning t{0.35f, kWideLeaf};
+    if (const char* e = getenv("CRT_SAH_NODE_COST")) t.node_cost = (float)atof(e);
+    if (const char* e = getenv("CRT_MAX_LEAF")) { int v = atoi(e); if (v >= 1 && v <= kWideLeaf) t.max_leaf = v; }
+    return t;
+}
+
 struct WideBuilder {
     std::vector<PrimRef>& refs;
     std::vector<BNode> nodes;
-    explicit WideBuilder(std::vector<PrimRef>& r) : refs(r) {}
+    WideTuning tune;
+    explicit WideBuilder(std::vector<PrimRef>& r) : refs(r), tune(wide_tuning()) {}
 
     int build(int first, int count) {
         int ni = (int)nodes.size();
@@ -265,7 +278,7 @@ struct WideBuilder {
         AABB box, cb; box.reset(); cb.reset();
         for (int i = first; i < first + count; i++) { box.add(refs[i].box); cb.addp(refs[i].c); }
         nodes[ni].box = box; nodes[ni].left = nodes[ni].right = -1; nodes[ni].first = first; nodes[ni].count = count;
-        if (count <= kWideLeaf) return ni;
+        if (count <= 1) return ni;
         int bestAxis = -1, bestSplit = -1; float bestCost = kFmax;
         for (int a = 0; a < 3; a++) {
             float ext = cb.hi[a] - cb.lo[a];
@@ -288,6 +301,11 @@ struct WideBuilder {
                 float cost = acc.area() * (float)c + rightArea[b + 1] * (float)rightCnt[b + 1];
                 if (cost < bestCost) { bestCost = cost; bestAxis = a; bestSplit = b; }
             }
+        }
+        if (count <= tune.max_leaf) {
+            const float a = box.area();
+            const float split_cost = (bestAxis >= 0 && a > 0.f) ? tune.node_cost + bestCost / a : kFmax;
+            if ((float)count <= split_cost) return ni;
         }
         int mid;
         if (bestAxis < 0) {
@@ -387,6 +405,23 @@ int build_wide(const crt_prim* prims, int n, const RefTree* ref, HostBVH& out) {
         }
         for (int k = nk - 1; k >= 0; k--)
             if (childPacked[k] >= 0) stack.push_back({kids[k], childPacked[k], it.depth + 1});
+    }
+    /* the quantised traversal node (layout.h QNode) derives child links from two base indices:
+     * internal children must be consecutive nodes and leaf children consecutive slots, in child order */
+    for (const Node4& nd : out.nodes) {
+        uint32_t next_node = 0, next_slot = 0; bool hn = false, hl = false;
+        for (int k = 0; k < 4; k++) {
+            const uint32_t l = nd.child[k];
+            if (l == kChildEmpty) continue;
+            if (l & kLeafFlag) {
+                const uint32_t start = l & kLeafStartMask, cnt = ((l >> kLeafCountShift) & 63u) + 1u;
+                if ((hl && start != next_slot) || cnt > (uint32_t)kWideLeaf) return CRT_ERR_BUILD;
+                hl = true; next_slot = start + cnt;
+            } else {
+                if (hn && l != next_node) return CRT_ERR_BUILD;
+                hn = true; next_node = l + 1;
+            }
+        }
     }
     return 0;
 }

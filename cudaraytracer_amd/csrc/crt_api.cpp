@@ -22,12 +22,16 @@
 #include <cstring>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 
 using namespace crt;
 
 namespace {
 constexpr int kMaxBounces = 16;
-constexpr int kCtrStride = 64;
+/* per sample pass: [0..15] queue sizes per bounce, [16..31] shadow-queue sizes, then 32 launches x 8 region
+ * fetch counters kFetchStride words apart */
+constexpr int kCtrFetch0 = 64;
+constexpr int kCtrStride = kCtrFetch0 + 32 * 8 * kFetchStride;
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 }
 
@@ -36,6 +40,7 @@ struct crt_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     bool counting = false, capture = false;
+    bool use_qnodes = true;      /* CRT_NO_QNODES=1 traverses the exact 128-byte nodes instead (A/B experiments) */
 
     std::vector<crt_prim> prims;
     std::vector<uint32_t> matid;
@@ -108,6 +113,7 @@ SceneView view_of(const crt_ctx* c) {
     SceneView v{};
     const char* b = (const char*)c->d_blob;
     v.nodes = (const Node4*)(b + c->hdr.off_nodes);
+    v.qnodes = (const QNode*)(b + c->hdr.off_qnodes);
     v.geom = (const Geom*)(b + c->hdr.off_geom);
     v.shade = (const Shade*)(b + c->hdr.off_shade);
     v.rank = (const uint32_t*)(b + c->hdr.off_rank);
@@ -155,6 +161,7 @@ int upload_prims(crt_ctx* c) {
 void layout_blob(BlobHeader& h) {
     size_t off = align_up(sizeof(BlobHeader), 256);
     h.off_nodes = off; off = align_up(off + (size_t)h.nnodes * sizeof(Node4), 256);
+    h.off_qnodes = off; off = align_up(off + (size_t)h.nnodes * sizeof(QNode), 256);
     h.off_geom = off; off = align_up(off + (size_t)h.nprims * sizeof(Geom), 256);
     h.off_shade = off; off = align_up(off + (size_t)h.nprims * sizeof(Shade), 256);
     h.off_rank = off; off = align_up(off + (size_t)h.nprims * 4, 256);
@@ -284,6 +291,7 @@ crt_ctx* crt_create(int device, int* err) {
     hipMemset(c->d_status, 0, 4);
     hipMemset(c->d_testctr, 0, 6 * sizeof(unsigned long long));
     c->grid_blocks = trace_grid_blocks(device);
+    c->use_qnodes = getenv("CRT_NO_QNODES") == nullptr;
     if (err) *err = CRT_OK;
     return c;
 }
@@ -406,6 +414,7 @@ int crt_bvh_build(crt_ctx* c, int mode) {
     if (h.nmats) HIPCHECK(c, hipMemcpyAsync(b + h.off_mats, c->mats.data(), (size_t)h.nmats * sizeof(Material), hipMemcpyHostToDevice, c->stream));
     launch_pack_prims(c->d_prims, c->d_matid, (const uint32_t*)(b + h.off_slot_of), (uint32_t)n, (Geom*)(b + h.off_geom),
                       (Shade*)(b + h.off_shade), c->stream);
+    if (mode == CRT_BVH_WIDE) launch_quantize((const Node4*)(b + h.off_nodes), h.nnodes, (QNode*)(b + h.off_qnodes), c->stream);
     HIPCHECK(c, hipGetLastError());
     HIPCHECK(c, hipStreamSynchronize(c->stream));      /* host staging vectors go out of scope */
     rc = ensure(c, c->d_arrive, c->arrive_cap, (size_t)h.nnodes + 1);
@@ -429,6 +438,8 @@ int crt_bvh_refit(crt_ctx* c, int grow_only) {
     HIPCHECK(c, hipEventRecord(e0, c->stream));
     launch_refit((Node4*)(b + c->hdr.off_nodes), c->hdr.nnodes, (const Geom*)(b + c->hdr.off_geom), c->d_arrive,
                  (float*)(b + offsetof(BlobHeader, root_box)), grow_only ? 1 : 0, c->stream);
+    if (c->hdr.mode == CRT_BVH_WIDE)
+        launch_quantize((const Node4*)(b + c->hdr.off_nodes), c->hdr.nnodes, (QNode*)(b + c->hdr.off_qnodes), c->stream);
     HIPCHECK(c, hipGetLastError());
     HIPCHECK(c, hipEventRecord(e1, c->stream));
     HIPCHECK(c, hipMemcpyAsync(c->hdr.root_box, b + offsetof(BlobHeader, root_box), sizeof c->hdr.root_box, hipMemcpyDeviceToHost, c->stream));
@@ -580,18 +591,18 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
             fp.bounce = b;
             bind(cur);
             TraceArgs ta{};
-            ta.sv = sv; ta.rayO = fb.rayO; ta.rayD = fb.rayD; ta.count = ctr + b; ta.next = ctr + 32 + b;
+            ta.sv = sv; ta.rayO = fb.rayO; ta.rayD = fb.rayD; ta.count = ctr + b; ta.next = ctr + kCtrFetch0 + (2 * b) * 8 * kFetchStride;
             ta.hitSlot = c->hitSlot; ta.hitT = c->hitT; ta.shflag = nullptr; ta.scene_abs = c->scene_abs;
             ta.ovf = c->d_ovf; ta.ovf_depth = c->ovf_depth; ta.counters = c->d_testctr; ta.status = c->d_status;
-            launch_trace(ta, c->lights, TRACE_NEAREST, c->counting, c->grid_blocks, c->stream);
+            launch_trace(ta, c->lights, TRACE_NEAREST, c->counting, c->use_qnodes && c->hdr.mode == CRT_BVH_WIDE, c->grid_blocks, c->stream);
             mark(c, EV_TRACE_N);
             launch_shade(fp, fb, sv, c->lights, ctr + b, ctr + b + 1, ctr + 16 + b, c->stream);
             mark(c, EV_SHADE);
             if (c->lights.n > 0) {
                 TraceArgs ts = ta;
-                ts.rayO = c->shO; ts.rayD = c->shD; ts.count = ctr + 16 + b; ts.next = ctr + 48 + b;
+                ts.rayO = c->shO; ts.rayD = c->shD; ts.count = ctr + 16 + b; ts.next = ctr + kCtrFetch0 + (2 * b + 1) * 8 * kFetchStride;
                 ts.hitSlot = nullptr; ts.hitT = nullptr; ts.shflag = c->shflag; ts.counters = c->d_testctr + 3;
-                launch_trace(ts, c->lights, TRACE_SHADOW, c->counting, c->grid_blocks, c->stream);
+                launch_trace(ts, c->lights, TRACE_SHADOW, c->counting, c->use_qnodes && c->hdr.mode == CRT_BVH_WIDE, c->grid_blocks, c->stream);
                 mark(c, EV_TRACE_S);
             }
             launch_resolve(fb, c->lights, ctr + b, c->stream);
@@ -607,7 +618,8 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
         mark(c, EV_CONVERT);
     }
     HIPCHECK(c, hipGetLastError());
-    HIPCHECK(c, hipMemcpyAsync(c->h_ctr.data(), c->d_ctr, (size_t)spp * kCtrStride * 4, hipMemcpyDeviceToHost, c->stream));
+    for (int s = 0; s < spp; s++)      /* queue sizes only; the fetch counters stay on the device */
+        HIPCHECK(c, hipMemcpyAsync(&c->h_ctr[(size_t)s * kCtrStride], c->d_ctr + (size_t)s * kCtrStride, kCtrFetch0 * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     rc = check_status(c);
     if (rc) return rc;
@@ -685,20 +697,21 @@ static int trace_hook(crt_ctx* c, const float* org_dir, int n, int32_t* prim_out
 #define TH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { c->err = std::string(#call) + ": " + hipGetErrorString(e_); rc = CRT_ERR_HIP; goto done; } } while (0)
     TH(hipMalloc((void**)&d_od, (size_t)n * 24)); TH(hipMalloc((void**)&d_o, (size_t)n * 16)); TH(hipMalloc((void**)&d_d, (size_t)n * 16));
     TH(hipMalloc((void**)&d_slot, (size_t)n * 4)); TH(hipMalloc((void**)&d_id, (size_t)n * 4)); TH(hipMalloc((void**)&d_t, (size_t)n * 4));
-    TH(hipMalloc((void**)&d_flag, (size_t)n)); TH(hipMalloc((void**)&d_cnt, 8));
+    TH(hipMalloc((void**)&d_flag, (size_t)n)); TH(hipMalloc((void**)&d_cnt, (1 + 8 * kFetchStride) * 4 + 256));
     {
-        uint32_t cnt[2] = {(uint32_t)n, 0};
+        uint32_t cnt = (uint32_t)n;
         TH(hipMemcpyAsync(d_od, org_dir, (size_t)n * 24, hipMemcpyHostToDevice, c->stream));
-        TH(hipMemcpyAsync(d_cnt, cnt, 8, hipMemcpyHostToDevice, c->stream));
+        TH(hipMemsetAsync(d_cnt, 0, (1 + 8 * kFetchStride) * 4 + 256, c->stream));
+        TH(hipMemcpyAsync(d_cnt, &cnt, 4, hipMemcpyHostToDevice, c->stream));
         TH(hipMemsetAsync(d_flag, 0, (size_t)n, c->stream));
         launch_pack_rays(d_od, (uint32_t)n, d_o, d_d, c->stream);
         TraceArgs ta{};
-        ta.sv = view_of(c); ta.rayO = d_o; ta.rayD = d_d; ta.count = d_cnt; ta.next = d_cnt + 1;
+        ta.sv = view_of(c); ta.rayO = d_o; ta.rayD = d_d; ta.count = d_cnt; ta.next = d_cnt + 64;
         ta.hitSlot = d_slot; ta.hitT = d_t; ta.shflag = d_flag; ta.scene_abs = c->scene_abs;
         ta.ovf = c->d_ovf; ta.ovf_depth = c->ovf_depth; ta.counters = c->d_testctr; ta.status = c->d_status;
         if (c->counting) TH(hipMemsetAsync(c->d_testctr, 0, 6 * sizeof(unsigned long long), c->stream));
         LightsParam dummy{}; dummy.n = 1;          /* light 0 directional: the Ray.cu:650-656 predicate */
-        launch_trace(ta, dummy, shadow_out ? TRACE_SHADOW : TRACE_NEAREST, c->counting, c->grid_blocks, c->stream);
+        launch_trace(ta, dummy, shadow_out ? TRACE_SHADOW : TRACE_NEAREST, c->counting, c->use_qnodes && c->hdr.mode == CRT_BVH_WIDE, c->grid_blocks, c->stream);
         TH(hipGetLastError());
         if (shadow_out) TH(hipMemcpyAsync(shadow_out, d_flag, (size_t)n, hipMemcpyDeviceToHost, c->stream));
         else {
@@ -752,7 +765,7 @@ int crt_blob_import_device(crt_ctx* c, const void* dev_ptr, size_t bytes) {
     HIPCHECK(c, hipMemcpy(&h, dev_ptr, sizeof h, hipMemcpyDeviceToHost));
     if (h.magic != kBlobMagic || h.version != kBlobVersion || h.total_bytes != bytes) return fail(c, CRT_ERR_ARG, "crt_blob_import_device: not a scene blob of this version/size");
     BlobHeader chk = h; layout_blob(chk);
-    if (chk.total_bytes != h.total_bytes || chk.off_mats != h.off_mats) return fail(c, CRT_ERR_ARG, "crt_blob_import_device: inconsistent header");
+    if (chk.total_bytes != h.total_bytes || chk.off_mats != h.off_mats || chk.off_qnodes != h.off_qnodes) return fail(c, CRT_ERR_ARG, "crt_blob_import_device: inconsistent header");
     if (dev_ptr != c->d_blob) {
         if (bytes > c->blob_cap || !c->d_blob) {
             if (c->d_blob) HIPCHECK(c, hipFree(c->d_blob));

@@ -9,9 +9,24 @@
 
 namespace crt {
 
+/* tunables (overridable with -D for A/B builds, see tools/build_variant.sh) */
+#ifndef CRT_STACK_DEPTH
+#define CRT_STACK_DEPTH 32
+#endif
+#ifndef CRT_REFILL_MIN_IDLE
+#define CRT_REFILL_MIN_IDLE 8
+#endif
+#ifndef CRT_TRACE_MIN_WAVES
+#define CRT_TRACE_MIN_WAVES 0          /* 0: let the compiler choose; n: __launch_bounds__(256, n) waves per SIMD */
+#endif
+#ifndef CRT_FETCH_CHUNK
+#define CRT_FETCH_CHUNK 64
+#endif
+constexpr int kFetchChunk = CRT_FETCH_CHUNK;       /* rays a wave takes from the queue per atomic */
+constexpr int kFetchStride = 64;       /* uint32 words between the 8 per-region fetch counters (256 B apart) */
 constexpr int kTraceBlock = 256;       /* 4 waves of 64 */
-constexpr int kStackDepth = 32;        /* per-lane entries in LDS: stack[depth][lane], conflict-free per wave */
-constexpr int kRefillMinIdle = 16;     /* a wave refills from the ray queue when >= this many lanes are idle */
+constexpr int kStackDepth = CRT_STACK_DEPTH;        /* per-lane entries in LDS: stack[depth][lane], conflict-free per wave */
+constexpr int kRefillMinIdle = CRT_REFILL_MIN_IDLE; /* a wave refills from the ray queue when >= this many lanes are idle */
 
 /* Camera basis of Ray.cu:684-689 plus the tile map of this rank. */
 struct FrameParams {
@@ -50,7 +65,7 @@ struct TraceArgs {
     SceneView sv;
     const float4* rayO; const float4* rayD;
     const uint32_t* count;       /* number of rays (device) */
-    uint32_t* next;              /* fetch counter (device, zeroed) */
+    uint32_t* next;              /* 8 fetch counters, kFetchStride words apart (device, zeroed) */
     int32_t* hitSlot; float* hitT;           /* NEAREST outputs */
     uint8_t* shflag;                         /* SHADOW output, indexed by the target in rayO.w */
     float scene_abs;             /* max |coordinate| of the root box: scales the slab-test pad */
@@ -60,7 +75,8 @@ struct TraceArgs {
 };
 
 int trace_grid_blocks(int device);
-void launch_trace(const TraceArgs& a, const LightsParam& lights, int mode, bool counting, int blocks, hipStream_t s);
+void launch_trace(const TraceArgs& a, const LightsParam& lights, int mode, bool counting, bool quantised, int blocks, hipStream_t s);
+void launch_quantize(const Node4* nodes, uint32_t nnodes, QNode* qnodes, hipStream_t s);
 void launch_gen_primary(const FrameParams& fp, const FrameBuffers& fb, uint32_t* count, hipStream_t s);
 void launch_shade(const FrameParams& fp, const FrameBuffers& fb, const SceneView& sv, const LightsParam& lights,
                   const uint32_t* count, uint32_t* next_count, uint32_t* shadow_count, hipStream_t s);

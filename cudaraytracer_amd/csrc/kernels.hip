@@ -91,9 +91,14 @@ CRT_DEV bool sphere_test(const GeomRec& g, const vec3& o, const vec3& d, float& 
         ta = t0_; tb = t1_; la = l0_; lb = l1_;                 \
     }
 
-template <int MODE, bool COUNT>
-__global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs A, LightsParam LP) {
-    __shared__ uint32_t s_stack[kStackDepth][kTraceBlock];
+#if CRT_TRACE_MIN_WAVES > 0
+#define CRT_TRACE_BOUNDS __launch_bounds__(kTraceBlock, CRT_TRACE_MIN_WAVES)
+#else
+#define CRT_TRACE_BOUNDS __launch_bounds__(kTraceBlock)
+#endif
+template <int MODE, bool COUNT, bool QN>
+__global__ CRT_TRACE_BOUNDS void k_trace(TraceArgs A, LightsParam LP) {
+    __shared__ uint32_t s_stack[kStackDepth + 1][kTraceBlock];   /* last row: write-only trash for the branch-free push */
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const uint32_t total = *A.count;
@@ -101,7 +106,12 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs A, LightsParam 
     uint32_t* ovf = A.ovf + (size_t)gthread * (size_t)(A.ovf_depth > 0 ? A.ovf_depth : 0);
 
     bool active = false;
-    bool exhausted = false;
+    bool exhausted = false;          /* wave-uniform: the queue has no more chunks for this wave */
+    uint32_t cnext = 0, cend = 0;    /* wave-uniform: this wave's private chunk [cnext, cend) */
+    /* HW_REG_XCC_ID (id 20), bits [3:0]: which XCD this wave runs on.  Used for L2 affinity only. */
+    const uint32_t xcd = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
+    const uint32_t per_region = (((total + 7u) >> 3) + 63u) & ~63u;
+    uint32_t region_k = 0;           /* wave-uniform: regions (starting at this XCD's) already found empty */
     vec3 o, d;
     float ix = 0, iy = 0, iz = 0, ax = 0, ay = 0, az = 0, bx = 0, by = 0, bz = 0;
     float tbest = 0;
@@ -136,17 +146,42 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs A, LightsParam 
     }
 
     for (;;) {
-        /* ---- refill idle lanes from the queue ---- */
+        /* ---- refill idle lanes: each wave owns a private chunk of the queue and takes a new one
+         *      with ONE atomic when it runs dry (per-refill atomics on the single fetch counter
+         *      serialise at ~10 ns each and were the limit of this kernel) ---- */
         if (!exhausted) {
             const unsigned long long idle = __ballot(!active);
             const int nidle = __popcll(idle);
             if (nidle >= kRefillMinIdle) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(A.next, (uint32_t)nidle);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (!active) {
-                    const uint32_t idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                    if (idx < total) {
+                if (cnext >= cend) {
+                    /* the queue is cut into 8 contiguous regions, one fetch counter each (256 B apart).
+                     * A wave starts in the region of its own XCD -- the XCD's L2 then serves one part
+                     * of the image / one part of the secondary rays -- and moves on to the next
+                     * region when one is used up, so that no XCD idles at the tail. */
+                    bool got = false;
+                    while (region_k < 8 && !got) {
+                        const uint32_t r = (xcd + region_k) & 7u;
+                        const uint32_t rbeg = r * per_region;
+                        const uint32_t rend = rbeg + per_region < total ? rbeg + per_region : total;
+                        uint32_t base = 0xffffffffu;
+                        if (rbeg < rend) {
+                            if (lane == 0) base = atomicAdd(A.next + r * kFetchStride, (uint32_t)kFetchChunk);
+                            base = __builtin_amdgcn_readfirstlane(base);
+                        }
+                        if (rbeg < rend && base < rend - rbeg) {
+                            cnext = rbeg + base;
+                            cend = cnext + (uint32_t)kFetchChunk < rend ? cnext + (uint32_t)kFetchChunk : rend;
+                            got = true;
+                        } else region_k++;
+                    }
+                    if (!got) exhausted = true;
+                }
+                if (!exhausted) {
+                    const uint32_t idx = cnext + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                    const uint32_t take = (uint32_t)nidle < cend - cnext ? (uint32_t)nidle : cend - cnext;
+                    const bool mine = !active && idx < cend;
+                    cnext += take;
+                    if (mine) {
                         const float4 ro = A.rayO[idx], rd = A.rayD[idx];
                         if (MODE == TRACE_NEAREST && __float_as_uint(rd.w) == 0xffffffffu) {
                             A.hitSlot[idx] = -3;            /* hole in the primary queue: pixel outside the frame */
@@ -174,7 +209,6 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs A, LightsParam 
                         }
                     }
                 }
-                if (base + (uint32_t)nidle >= total) exhausted = true;
             }
         }
         if (__ballot(active) == 0ull) { if (exhausted) break; else continue; }
@@ -188,35 +222,101 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(TraceArgs A, LightsParam 
             bool finish = false;
             if (n_node >= n_prim) {
                 if (want_node) {
-                    const float4* np = reinterpret_cast<const float4*>(A.sv.nodes + cur);
-                    const float4 lox = np[0], loy = np[1], loz = np[2], hix = np[3], hiy = np[4], hiz = np[5];
-                    const uint4 ch = reinterpret_cast<const uint4*>(np)[6];
                     float tn0, tn1, tn2, tn3;
-#define SLAB(K, LX, LY, LZ, HX, HY, HZ, C)                                                      \
+                    uint32_t c0, c1, c2, c3;
+#define SLAB_T(K, X0, X1, Y0, Y1, Z0, Z1, C)                                                    \
     {                                                                                           \
-        const float x0 = fmaf(LX, ix, -ax), x1 = fmaf(HX, ix, -bx);                             \
-        const float y0 = fmaf(LY, iy, -ay), y1 = fmaf(HY, iy, -by);                             \
-        const float z0 = fmaf(LZ, iz, -az), z1 = fmaf(HZ, iz, -bz);                             \
-        const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), -1.0001e-4f)); \
-        const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tbest)); \
+        const float tn = fmaxf(fmaxf(fminf(X0, X1), fminf(Y0, Y1)), fmaxf(fminf(Z0, Z1), -1.0001e-4f)); \
+        const float tf = fminf(fminf(fmaxf(X0, X1), fmaxf(Y0, Y1)), fminf(fmaxf(Z0, Z1), tbest)); \
         K = ((C) != kChildEmpty && tn <= tf) ? tn : INFINITY;                                   \
         if (COUNT && (C) != kChildEmpty) nbox++;                                                \
     }
-                    SLAB(tn0, lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, ch.x)
-                    SLAB(tn1, lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, ch.y)
-                    SLAB(tn2, lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, ch.z)
-                    SLAB(tn3, lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ch.w)
+                    if (QN) {
+                        /* quantised node: 3 x 16 B per lane.  child plane t = q * (s*inv) + (o*inv - a) */
+                        const uint4* qp = reinterpret_cast<const uint4*>(A.sv.qnodes + cur);
+                        const uint4 w0 = qp[0], w1 = qp[1], w2 = qp[2];
+                        const uint32_t em = w0.w;
+                        const float nox = __uint_as_float(w0.x), noy = __uint_as_float(w0.y), noz = __uint_as_float(w0.z);
+                        const float sx = __uint_as_float((em & 0xffu) << 23) * ix;
+                        const float sy = __uint_as_float(((em >> 8) & 0xffu) << 23) * iy;
+                        const float sz = __uint_as_float(((em >> 16) & 0xffu) << 23) * iz;
+                        const float oax = fmaf(nox, ix, -ax), obx = fmaf(nox, ix, -bx);
+                        const float oay = fmaf(noy, iy, -ay), oby = fmaf(noy, iy, -by);
+                        const float oaz = fmaf(noz, iz, -az), obz = fmaf(noz, iz, -bz);
+                        const uint32_t meta = em >> 24;
+                        const uint32_t k0 = meta & 3u, k1 = (meta >> 2) & 3u, k2 = (meta >> 4) & 3u, k3 = (meta >> 6) & 3u;
+                        const uint32_t bs = w1.y;
+                        const uint32_t n0 = ((bs >> 24) & 3u) + 1u, n1 = ((bs >> 26) & 3u) + 1u, n2 = ((bs >> 28) & 3u) + 1u, n3 = ((bs >> 30) & 3u) + 1u;
+                        const uint32_t s0 = bs & kQSlotMask;
+                        const uint32_t s1 = s0 + (k0 == 2u ? n0 : 0u), s2 = s1 + (k1 == 2u ? n1 : 0u), s3 = s2 + (k2 == 2u ? n2 : 0u);
+                        const uint32_t i0 = w1.x;
+                        const uint32_t i1 = i0 + (k0 == 1u ? 1u : 0u), i2 = i1 + (k1 == 1u ? 1u : 0u), i3 = i2 + (k2 == 1u ? 1u : 0u);
+                        c0 = k0 == 1u ? i0 : (k0 == 2u ? (kLeafFlag | ((n0 - 1u) << kLeafCountShift) | s0) : kChildEmpty);
+                        c1 = k1 == 1u ? i1 : (k1 == 2u ? (kLeafFlag | ((n1 - 1u) << kLeafCountShift) | s1) : kChildEmpty);
+                        c2 = k2 == 1u ? i2 : (k2 == 2u ? (kLeafFlag | ((n2 - 1u) << kLeafCountShift) | s2) : kChildEmpty);
+                        c3 = k3 == 1u ? i3 : (k3 == 2u ? (kLeafFlag | ((n3 - 1u) << kLeafCountShift) | s3) : kChildEmpty);
+#define QB(W, K) ((float)(((W) >> (8 * (K))) & 0xffu))
+#define SLAB_Q(K, TN, C)                                                                         \
+    {                                                                                            \
+        const float x0 = fmaf(QB(w1.z, K), sx, oax), x1 = fmaf(QB(w2.y, K), sx, obx);            \
+        const float y0 = fmaf(QB(w1.w, K), sy, oay), y1 = fmaf(QB(w2.z, K), sy, oby);            \
+        const float z0 = fmaf(QB(w2.x, K), sz, oaz), z1 = fmaf(QB(w2.w, K), sz, obz);            \
+        SLAB_T(TN, x0, x1, y0, y1, z0, z1, C)                                                    \
+    }
+                        SLAB_Q(0, tn0, c0)
+                        SLAB_Q(1, tn1, c1)
+                        SLAB_Q(2, tn2, c2)
+                        SLAB_Q(3, tn3, c3)
+#undef SLAB_Q
+#undef QB
+                    } else {
+                        const float4* np = reinterpret_cast<const float4*>(A.sv.nodes + cur);
+                        const float4 lox = np[0], loy = np[1], loz = np[2], hix = np[3], hiy = np[4], hiz = np[5];
+                        const uint4 ch = reinterpret_cast<const uint4*>(np)[6];
+#ifdef CRT_EXPERIMENT_EXTRA_LOADS   /* timing experiment only: is the vector L1's access rate the limit? */
+                        for (int e_ = 0; e_ < CRT_EXPERIMENT_EXTRA_LOADS; e_++) {
+                            typedef float f4v_ __attribute__((ext_vector_type(4)));
+                            const f4v_ x_ = reinterpret_cast<const volatile f4v_*>(np)[7];
+                            asm volatile("" ::"v"(x_));
+                        }
+#endif
+#define SLAB(K, LX, LY, LZ, HX, HY, HZ, C)                                                       \
+    {                                                                                            \
+        const float x0 = fmaf(LX, ix, -ax), x1 = fmaf(HX, ix, -bx);                              \
+        const float y0 = fmaf(LY, iy, -ay), y1 = fmaf(HY, iy, -by);                              \
+        const float z0 = fmaf(LZ, iz, -az), z1 = fmaf(HZ, iz, -bz);                              \
+        SLAB_T(K, x0, x1, y0, y1, z0, z1, C)                                                     \
+    }
+                        SLAB(tn0, lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, ch.x)
+                        SLAB(tn1, lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, ch.y)
+                        SLAB(tn2, lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, ch.z)
+                        SLAB(tn3, lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ch.w)
 #undef SLAB
-                    uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
+                        c0 = ch.x; c1 = ch.y; c2 = ch.z; c3 = ch.w;
+                    }
+#undef SLAB_T
                     CSWAP(tn0, c0, tn1, c1)
                     CSWAP(tn2, c2, tn3, c3)
                     CSWAP(tn0, c0, tn2, c2)
                     CSWAP(tn1, c1, tn3, c3)
                     CSWAP(tn1, c1, tn2, c2)
-                    /* nearest child becomes the next item; the others go on the stack far-first */
-                    if (tn3 < INFINITY) PUSH_ITEM(c3)
-                    if (tn2 < INFINITY) PUSH_ITEM(c2)
-                    if (tn1 < INFINITY) PUSH_ITEM(c1)
+                    /* nearest child becomes the next item; the others go on the stack far-first.
+                     * After the sort the children that were hit form a prefix, so the three stores
+                     * go to computed rows (or to the trash row) without branches. */
+                    const int npush = (tn1 < INFINITY ? 1 : 0) + (tn2 < INFINITY ? 1 : 0) + (tn3 < INFINITY ? 1 : 0);
+                    if (sp + 3 <= kStackDepth) {
+                        const int r1 = npush >= 1 ? sp + npush - 1 : kStackDepth;
+                        const int r2 = npush >= 2 ? sp + npush - 2 : kStackDepth;
+                        const int r3 = npush >= 3 ? sp : kStackDepth;
+                        s_stack[r1][tid] = c1;
+                        s_stack[r2][tid] = c2;
+                        s_stack[r3][tid] = c3;
+                        sp += npush;
+                    } else {                   /* deep trees only: spill rows live in HBM */
+                        if (tn3 < INFINITY) PUSH_ITEM(c3)
+                        if (tn2 < INFINITY) PUSH_ITEM(c2)
+                        if (tn1 < INFINITY) PUSH_ITEM(c1)
+                    }
                     if (tn0 < INFINITY) {
                         if (c0 & kLeafFlag) { lp = c0 & kLeafStartMask; lend = lp + ((c0 >> kLeafCountShift) & 63u) + 1u; }
                         else cur = c0;
@@ -286,21 +386,98 @@ int trace_grid_blocks(int device) {
     /* persistent grid = what is resident at once: limited by the 32 KB LDS stack per block (5 blocks
      * per CU) and by the kernel's VGPR allocation; ask the runtime for the tighter of the two */
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<TRACE_NEAREST, false>, kTraceBlock, 0) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<TRACE_NEAREST, false, true>, kTraceBlock, 0) != hipSuccess || per_cu < 1)
         per_cu = 4;
-    if (per_cu > 5) per_cu = 5;
+    if (per_cu > 8) per_cu = 8;
     return p.multiProcessorCount * per_cu;
 }
 
-void launch_trace(const TraceArgs& a, const LightsParam& lights, int mode, bool counting, int blocks, hipStream_t s) {
-    dim3 g(blocks), b(kTraceBlock);
-    if (mode == TRACE_NEAREST) {
-        if (counting) hipLaunchKernelGGL((k_trace<TRACE_NEAREST, true>), g, b, 0, s, a, lights);
-        else hipLaunchKernelGGL((k_trace<TRACE_NEAREST, false>), g, b, 0, s, a, lights);
+template <int MODE>
+static void launch_trace_mode(const TraceArgs& a, const LightsParam& lights, bool counting, bool quantised, dim3 g, dim3 b, hipStream_t s) {
+    if (quantised) {
+        if (counting) hipLaunchKernelGGL((k_trace<MODE, true, true>), g, b, 0, s, a, lights);
+        else hipLaunchKernelGGL((k_trace<MODE, false, true>), g, b, 0, s, a, lights);
     } else {
-        if (counting) hipLaunchKernelGGL((k_trace<TRACE_SHADOW, true>), g, b, 0, s, a, lights);
-        else hipLaunchKernelGGL((k_trace<TRACE_SHADOW, false>), g, b, 0, s, a, lights);
+        if (counting) hipLaunchKernelGGL((k_trace<MODE, true, false>), g, b, 0, s, a, lights);
+        else hipLaunchKernelGGL((k_trace<MODE, false, false>), g, b, 0, s, a, lights);
     }
+}
+void launch_trace(const TraceArgs& a, const LightsParam& lights, int mode, bool counting, bool quantised, int blocks, hipStream_t s) {
+    dim3 g(blocks), b(kTraceBlock);
+    if (mode == TRACE_NEAREST) launch_trace_mode<TRACE_NEAREST>(a, lights, counting, quantised, g, b, s);
+    else launch_trace_mode<TRACE_SHADOW>(a, lights, counting, quantised, g, b, s);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * k_quantize: Node4 (exact child bounds) -> QNode (8-bit bounds relative to the node's own box,
+ * rounded outward; checked in double so that every quantised box contains the exact one).
+ * Runs after every build and refit of the wide tree.
+ * ------------------------------------------------------------------------------------------ */
+__global__ __launch_bounds__(256) void k_quantize(const Node4* nodes, uint32_t nnodes, QNode* qnodes) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nnodes) return;
+    const Node4& nd = nodes[i];
+    float lo[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
+    float hi[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+    for (int k = 0; k < 4; k++) {
+        if (nd.child[k] == kChildEmpty) continue;
+        lo[0] = fminf(lo[0], nd.lox[k]); lo[1] = fminf(lo[1], nd.loy[k]); lo[2] = fminf(lo[2], nd.loz[k]);
+        hi[0] = fmaxf(hi[0], nd.hix[k]); hi[1] = fmaxf(hi[1], nd.hiy[k]); hi[2] = fmaxf(hi[2], nd.hiz[k]);
+    }
+    QNode q;
+    uint8_t ex[3];
+    for (int a = 0; a < 3; a++) {
+        const float clo[4] = {a == 0 ? nd.lox[0] : a == 1 ? nd.loy[0] : nd.loz[0], a == 0 ? nd.lox[1] : a == 1 ? nd.loy[1] : nd.loz[1],
+                              a == 0 ? nd.lox[2] : a == 1 ? nd.loy[2] : nd.loz[2], a == 0 ? nd.lox[3] : a == 1 ? nd.loy[3] : nd.loz[3]};
+        const float chi[4] = {a == 0 ? nd.hix[0] : a == 1 ? nd.hiy[0] : nd.hiz[0], a == 0 ? nd.hix[1] : a == 1 ? nd.hiy[1] : nd.hiz[1],
+                              a == 0 ? nd.hix[2] : a == 1 ? nd.hiy[2] : nd.hiz[2], a == 0 ? nd.hix[3] : a == 1 ? nd.hiy[3] : nd.hiz[3]};
+        const float o = lo[a] <= hi[a] ? lo[a] : 0.f;
+        const float ext = lo[a] <= hi[a] ? hi[a] - lo[a] : 0.f;
+        /* smallest power of two s with 254*s >= extent (one code of headroom for outward rounding) */
+        int e = 0;
+        (void)frexpf(ext / 254.0f, &e);
+        float sc = ldexpf(1.0f, e);
+        if (!(ext > 0.f)) sc = ldexpf(1.0f, -60);
+        for (int attempt = 0; attempt < 4; attempt++) {
+            bool fits = true;
+            for (int k = 0; k < 4; k++) {
+                uint32_t ql = 0, qh = 0;
+                if (nd.child[k] != kChildEmpty) {
+                    float fl = floorf((clo[k] - o) / sc), fh = ceilf((chi[k] - o) / sc);
+                    fl = fminf(fmaxf(fl, 0.f), 255.f); fh = fminf(fmaxf(fh, 0.f), 255.f);
+                    ql = (uint32_t)fl; qh = (uint32_t)fh;
+                    while (ql > 0 && (double)o + (double)ql * (double)sc > (double)clo[k]) ql--;
+                    while (qh < 255 && (double)o + (double)qh * (double)sc < (double)chi[k]) qh++;
+                    if ((double)o + (double)ql * (double)sc > (double)clo[k] || (double)o + (double)qh * (double)sc < (double)chi[k]) fits = false;
+                }
+                q.qlo[a][k] = (uint8_t)ql; q.qhi[a][k] = (uint8_t)qh;
+            }
+            if (fits) break;
+            sc *= 2.0f;
+        }
+        ex[a] = (uint8_t)((__float_as_uint(sc) >> 23) & 0xffu);
+        if (a == 0) q.ox = o; else if (a == 1) q.oy = o; else q.oz = o;
+    }
+    q.ex = ex[0]; q.ey = ex[1]; q.ez = ex[2];
+    uint32_t meta = 0, base_node = 0, base_slot = 0, counts = 0;
+    bool have_node = false, have_leaf = false;
+    for (int k = 0; k < 4; k++) {
+        const uint32_t l = nd.child[k];
+        if (l == kChildEmpty) continue;
+        if (l & kLeafFlag) {
+            meta |= 2u << (2 * k);
+            if (!have_leaf) { base_slot = l & kLeafStartMask; have_leaf = true; }
+            counts |= (((l >> kLeafCountShift) & 63u) & 3u) << (2 * k);
+        } else {
+            meta |= 1u << (2 * k);
+            if (!have_node) { base_node = l; have_node = true; }
+        }
+    }
+    q.meta = (uint8_t)meta; q.base_node = base_node; q.base_slot = (base_slot & kQSlotMask) | (counts << 24);
+    qnodes[i] = q;
+}
+void launch_quantize(const Node4* nodes, uint32_t nnodes, QNode* qnodes, hipStream_t s) {
+    if (nnodes) hipLaunchKernelGGL(k_quantize, dim3((nnodes + 255u) / 256u), dim3(256), 0, s, nodes, nnodes, qnodes);
 }
 
 /* ------------------------------------------------------------------------------------------

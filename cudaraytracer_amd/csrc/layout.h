@@ -3,7 +3,14 @@
  * One contiguous device allocation, so that replicating the scene to another GPU is a single
  * broadcast.  Sections (all 256-byte aligned, offsets in BlobHeader):
  *
- *   nodes   nnodes x 128 B   4-wide BVH node: child bounds SoA + child links + parent link
+ *   nodes   nnodes x 128 B   4-wide BVH node: exact child bounds SoA + child links + parent link.
+ *                            Master copy: refit and dumps work on it; the kernels traverse it only
+ *                            for the reference topology.
+ *   qnodes  nnodes x  48 B   the same tree quantised for traversal (wide mode): node origin + per-axis
+ *                            power-of-two scale, 8-bit conservative child bounds, child links
+ *                            implied by two base indices.  3 x 16-byte loads per lane per visit
+ *                            instead of 7: the traversal is bound by the vector L1's access rate
+ *                            (profiles/r01b_vote_sched.md), not by bytes.
  *   geom    nprims x  48 B   hit-test record, indexed by SLOT (leaf order of the packed tree)
  *                              triangle: v1.xyz v2.xyz v3.xyz Ng.xyz   (Ng precomputed exactly as Ray.cu:145)
  *                              sphere:   c.xyz r | dot(c,c) r*r 0 0 | 0 SPHERE_TAG 0 0
@@ -23,7 +30,7 @@
 namespace crt {
 
 constexpr uint32_t kBlobMagic = 0x43525442u;   /* "CRTB" */
-constexpr uint32_t kBlobVersion = 2;
+constexpr uint32_t kBlobVersion = 3;
 constexpr uint32_t kSphereTag = 0x7fc5fe3eu;   /* quiet NaN with a payload no arithmetic produces */
 constexpr uint32_t kChildEmpty = 0xffffffffu;
 constexpr uint32_t kLeafFlag = 0x80000000u;
@@ -47,6 +54,23 @@ struct alignas(128) Node4 {
 };
 static_assert(sizeof(Node4) == 128, "Node4 must be 128 bytes");
 
+/* Quantised traversal node.  Child k's box is [o + qlo*s, o + qhi*s] per axis with s = 2^(e-127)
+ * taken from the exponent byte; quantisation rounds outward, so the box contains the exact one.
+ * kind (2 bits per child in `meta`): 0 empty, 1 internal, 2 leaf.  Internal children are the
+ * consecutive nodes base_node, base_node+1, ... in child order; leaf children own consecutive
+ * primitive slots starting at base_slot (low 24 bits), child k having ((base_slot >> (24+2k)) & 3) + 1
+ * of them. */
+struct alignas(16) QNode {
+    float ox, oy, oz;
+    uint8_t ex, ey, ez, meta;
+    uint32_t base_node;
+    uint32_t base_slot;
+    uint8_t qlo[3][4];
+    uint8_t qhi[3][4];
+};
+static_assert(sizeof(QNode) == 48, "QNode must be 48 bytes");
+constexpr uint32_t kQSlotMask = (1u << 24) - 1u;
+
 struct alignas(16) Geom { float w[12]; };
 struct alignas(16) Shade { float n[9]; uint32_t mat; uint32_t pad[2]; };
 struct alignas(16) Material { float ambient[3], diffuse[3], specular[3], reflective[3]; float shininess; float pad[3]; };
@@ -57,16 +81,17 @@ struct BlobHeader {
     uint32_t nprims, nnodes, nmats, depth;
     uint32_t mode;            /* CRT_BVH_WIDE / CRT_BVH_REFERENCE */
     uint32_t root_is_leaf;    /* reference topology with <=64 primitives: a single leaf (Ray.cu:186-188) */
-    uint64_t off_nodes, off_geom, off_shade, off_rank, off_sidx, off_slot_of, off_mats;
+    uint64_t off_nodes, off_qnodes, off_geom, off_shade, off_rank, off_sidx, off_slot_of, off_mats;
     uint64_t total_bytes;
     float root_box[6];        /* minX,maxX,minY,maxY,minZ,maxZ written by build and refit */
-    uint32_t pad[10];
+    uint32_t pad[8];
 };
 static_assert(sizeof(BlobHeader) % 16 == 0, "header alignment");
 
 /* Device-side view: raw pointers into the blob. */
 struct SceneView {
     const Node4* nodes;
+    const QNode* qnodes;
     const Geom* geom;
     const Shade* shade;
     const uint32_t* rank;
