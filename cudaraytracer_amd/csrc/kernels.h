@@ -19,6 +19,13 @@ namespace crt {
 #ifndef CRT_TRACE_MIN_WAVES
 #define CRT_TRACE_MIN_WAVES 0          /* 0: let the compiler choose; n: __launch_bounds__(256, n) waves per SIMD */
 #endif
+/* vote: a node step runs when n_node * PRIM_WEIGHT >= n_prim * NODE_WEIGHT (1:1 = plain majority) */
+#ifndef CRT_VOTE_PRIM_WEIGHT
+#define CRT_VOTE_PRIM_WEIGHT 1
+#endif
+#ifndef CRT_VOTE_NODE_WEIGHT
+#define CRT_VOTE_NODE_WEIGHT 3
+#endif
 #ifndef CRT_FETCH_CHUNK
 #define CRT_FETCH_CHUNK 64
 #endif

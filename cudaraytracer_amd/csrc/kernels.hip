@@ -204,6 +204,13 @@ __global__ CRT_TRACE_BOUNDS void k_trace(TraceArgs A, LightsParam LP) {
                             ax = (o.x + px) * ix; bx = (o.x - px) * ix;
                             ay = (o.y + py) * iy; by = (o.y - py) * iy;
                             az = (o.z + pz) * iz; bz = (o.z - pz) * iz;
+                            if (QN) {
+                                /* quantised path: planes are picked by the direction's sign instead of
+                                 * min/max per pair, so keep the offsets as (near, far) instead of (lo, hi) */
+                                if (ix < 0.f) { const float t_ = ax; ax = bx; bx = t_; }
+                                if (iy < 0.f) { const float t_ = ay; ay = by; by = t_; }
+                                if (iz < 0.f) { const float t_ = az; az = bz; bz = t_; }
+                            }
                             tbest = 1000000000.0f; best = -1; cur = 0; sp = 0; found = 0; lp = lend = 0;
                             active = true;
                         }
@@ -220,7 +227,7 @@ __global__ CRT_TRACE_BOUNDS void k_trace(TraceArgs A, LightsParam LP) {
             const int n_node = __popcll(__ballot(want_node));
             const int n_prim = __popcll(__ballot(want_prim));
             bool finish = false;
-            if (n_node >= n_prim) {
+            if (n_node * CRT_VOTE_PRIM_WEIGHT >= n_prim * CRT_VOTE_NODE_WEIGHT) {
                 if (want_node) {
                     float tn0, tn1, tn2, tn3;
                     uint32_t c0, c1, c2, c3;
@@ -232,36 +239,33 @@ __global__ CRT_TRACE_BOUNDS void k_trace(TraceArgs A, LightsParam LP) {
         if (COUNT && (C) != kChildEmpty) nbox++;                                                \
     }
                     if (QN) {
-                        /* quantised node: 3 x 16 B per lane.  child plane t = q * (s*inv) + (o*inv - a) */
+                        /* quantised node: 4 x 16 B per lane.  child plane t = q * (s*inv) + (o*inv - off);
+                         * near/far planes chosen per axis by the sign of the direction */
                         const uint4* qp = reinterpret_cast<const uint4*>(A.sv.qnodes + cur);
-                        const uint4 w0 = qp[0], w1 = qp[1], w2 = qp[2];
+                        const uint4 w0 = qp[0], w1 = qp[1], w2 = qp[2], w3 = qp[3];
                         const uint32_t em = w0.w;
                         const float nox = __uint_as_float(w0.x), noy = __uint_as_float(w0.y), noz = __uint_as_float(w0.z);
                         const float sx = __uint_as_float((em & 0xffu) << 23) * ix;
                         const float sy = __uint_as_float(((em >> 8) & 0xffu) << 23) * iy;
                         const float sz = __uint_as_float(((em >> 16) & 0xffu) << 23) * iz;
-                        const float oax = fmaf(nox, ix, -ax), obx = fmaf(nox, ix, -bx);
-                        const float oay = fmaf(noy, iy, -ay), oby = fmaf(noy, iy, -by);
-                        const float oaz = fmaf(noz, iz, -az), obz = fmaf(noz, iz, -bz);
-                        const uint32_t meta = em >> 24;
-                        const uint32_t k0 = meta & 3u, k1 = (meta >> 2) & 3u, k2 = (meta >> 4) & 3u, k3 = (meta >> 6) & 3u;
-                        const uint32_t bs = w1.y;
-                        const uint32_t n0 = ((bs >> 24) & 3u) + 1u, n1 = ((bs >> 26) & 3u) + 1u, n2 = ((bs >> 28) & 3u) + 1u, n3 = ((bs >> 30) & 3u) + 1u;
-                        const uint32_t s0 = bs & kQSlotMask;
-                        const uint32_t s1 = s0 + (k0 == 2u ? n0 : 0u), s2 = s1 + (k1 == 2u ? n1 : 0u), s3 = s2 + (k2 == 2u ? n2 : 0u);
-                        const uint32_t i0 = w1.x;
-                        const uint32_t i1 = i0 + (k0 == 1u ? 1u : 0u), i2 = i1 + (k1 == 1u ? 1u : 0u), i3 = i2 + (k2 == 1u ? 1u : 0u);
-                        c0 = k0 == 1u ? i0 : (k0 == 2u ? (kLeafFlag | ((n0 - 1u) << kLeafCountShift) | s0) : kChildEmpty);
-                        c1 = k1 == 1u ? i1 : (k1 == 2u ? (kLeafFlag | ((n1 - 1u) << kLeafCountShift) | s1) : kChildEmpty);
-                        c2 = k2 == 1u ? i2 : (k2 == 2u ? (kLeafFlag | ((n2 - 1u) << kLeafCountShift) | s2) : kChildEmpty);
-                        c3 = k3 == 1u ? i3 : (k3 == 2u ? (kLeafFlag | ((n3 - 1u) << kLeafCountShift) | s3) : kChildEmpty);
+                        const float onx = fmaf(nox, ix, -ax), ofx = fmaf(nox, ix, -bx);
+                        const float ony = fmaf(noy, iy, -ay), ofy = fmaf(noy, iy, -by);
+                        const float onz = fmaf(noz, iz, -az), ofz = fmaf(noz, iz, -bz);
+                        const bool ngx = ix < 0.f, ngy = iy < 0.f, ngz = iz < 0.f;
+                        const uint32_t nwx = ngx ? w1.w : w1.x, fwx = ngx ? w1.x : w1.w;      /* qlo x,y,z = w1.xyz; qhi x,y,z = w1.w, w2.x, w2.y */
+                        const uint32_t nwy = ngy ? w2.x : w1.y, fwy = ngy ? w1.y : w2.x;
+                        const uint32_t nwz = ngz ? w2.y : w1.z, fwz = ngz ? w1.z : w2.y;
+                        c0 = w3.x; c1 = w3.y; c2 = w3.z; c3 = w3.w;
 #define QB(W, K) ((float)(((W) >> (8 * (K))) & 0xffu))
 #define SLAB_Q(K, TN, C)                                                                         \
     {                                                                                            \
-        const float x0 = fmaf(QB(w1.z, K), sx, oax), x1 = fmaf(QB(w2.y, K), sx, obx);            \
-        const float y0 = fmaf(QB(w1.w, K), sy, oay), y1 = fmaf(QB(w2.z, K), sy, oby);            \
-        const float z0 = fmaf(QB(w2.x, K), sz, oaz), z1 = fmaf(QB(w2.w, K), sz, obz);            \
-        SLAB_T(TN, x0, x1, y0, y1, z0, z1, C)                                                    \
+        const float tnx = fmaf(QB(nwx, K), sx, onx), tfx = fmaf(QB(fwx, K), sx, ofx);            \
+        const float tny = fmaf(QB(nwy, K), sy, ony), tfy = fmaf(QB(fwy, K), sy, ofy);            \
+        const float tnz = fmaf(QB(nwz, K), sz, onz), tfz = fmaf(QB(fwz, K), sz, ofz);            \
+        const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, -1.0001e-4f));                        \
+        const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tbest));                              \
+        TN = ((C) != kChildEmpty && tn <= tf) ? tn : INFINITY;                                   \
+        if (COUNT && (C) != kChildEmpty) nbox++;                                                 \
     }
                         SLAB_Q(0, tn0, c0)
                         SLAB_Q(1, tn1, c1)
@@ -458,22 +462,8 @@ __global__ __launch_bounds__(256) void k_quantize(const Node4* nodes, uint32_t n
         ex[a] = (uint8_t)((__float_as_uint(sc) >> 23) & 0xffu);
         if (a == 0) q.ox = o; else if (a == 1) q.oy = o; else q.oz = o;
     }
-    q.ex = ex[0]; q.ey = ex[1]; q.ez = ex[2];
-    uint32_t meta = 0, base_node = 0, base_slot = 0, counts = 0;
-    bool have_node = false, have_leaf = false;
-    for (int k = 0; k < 4; k++) {
-        const uint32_t l = nd.child[k];
-        if (l == kChildEmpty) continue;
-        if (l & kLeafFlag) {
-            meta |= 2u << (2 * k);
-            if (!have_leaf) { base_slot = l & kLeafStartMask; have_leaf = true; }
-            counts |= (((l >> kLeafCountShift) & 63u) & 3u) << (2 * k);
-        } else {
-            meta |= 1u << (2 * k);
-            if (!have_node) { base_node = l; have_node = true; }
-        }
-    }
-    q.meta = (uint8_t)meta; q.base_node = base_node; q.base_slot = (base_slot & kQSlotMask) | (counts << 24);
+    q.ex = ex[0]; q.ey = ex[1]; q.ez = ex[2]; q.pad0 = 0; q.pad1[0] = q.pad1[1] = 0;
+    for (int k = 0; k < 4; k++) q.child[k] = nd.child[k];
     qnodes[i] = q;
 }
 void launch_quantize(const Node4* nodes, uint32_t nnodes, QNode* qnodes, hipStream_t s) {

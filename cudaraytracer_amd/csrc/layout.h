@@ -6,11 +6,9 @@
  *   nodes   nnodes x 128 B   4-wide BVH node: exact child bounds SoA + child links + parent link.
  *                            Master copy: refit and dumps work on it; the kernels traverse it only
  *                            for the reference topology.
- *   qnodes  nnodes x  48 B   the same tree quantised for traversal (wide mode): node origin + per-axis
- *                            power-of-two scale, 8-bit conservative child bounds, child links
- *                            implied by two base indices.  3 x 16-byte loads per lane per visit
- *                            instead of 7: the traversal is bound by the vector L1's access rate
- *                            (profiles/r01b_vote_sched.md), not by bytes.
+ *   qnodes  nnodes x  64 B   the same tree quantised for traversal (wide mode): node origin + per-axis
+ *                            power-of-two scale, 8-bit conservative child bounds, explicit child
+ *                            links.  4 x 16-byte loads per lane per visit instead of 7.
  *   geom    nprims x  48 B   hit-test record, indexed by SLOT (leaf order of the packed tree)
  *                              triangle: v1.xyz v2.xyz v3.xyz Ng.xyz   (Ng precomputed exactly as Ray.cu:145)
  *                              sphere:   c.xyz r | dot(c,c) r*r 0 0 | 0 SPHERE_TAG 0 0
@@ -54,22 +52,20 @@ struct alignas(128) Node4 {
 };
 static_assert(sizeof(Node4) == 128, "Node4 must be 128 bytes");
 
-/* Quantised traversal node.  Child k's box is [o + qlo*s, o + qhi*s] per axis with s = 2^(e-127)
- * taken from the exponent byte; quantisation rounds outward, so the box contains the exact one.
- * kind (2 bits per child in `meta`): 0 empty, 1 internal, 2 leaf.  Internal children are the
- * consecutive nodes base_node, base_node+1, ... in child order; leaf children own consecutive
- * primitive slots starting at base_slot (low 24 bits), child k having ((base_slot >> (24+2k)) & 3) + 1
- * of them. */
+/* Quantised traversal node, 64 B = 4 x 16-byte loads per lane per visit (the exact node needs 7).
+ * Child k's box is [o + qlo*s, o + qhi*s] per axis with s = 2^(e-127) taken from the exponent
+ * byte; quantisation rounds outward, so the box contains the exact one.  Child links are the
+ * same 32-bit links as Node4::child (explicit: deriving them from base indices cost ~35 VALU
+ * instructions per visit in a kernel that is bound by VALU issue). */
 struct alignas(16) QNode {
     float ox, oy, oz;
-    uint8_t ex, ey, ez, meta;
-    uint32_t base_node;
-    uint32_t base_slot;
+    uint8_t ex, ey, ez, pad0;
     uint8_t qlo[3][4];
     uint8_t qhi[3][4];
+    uint32_t pad1[2];
+    uint32_t child[4];
 };
-static_assert(sizeof(QNode) == 48, "QNode must be 48 bytes");
-constexpr uint32_t kQSlotMask = (1u << 24) - 1u;
+static_assert(sizeof(QNode) == 64, "QNode must be 64 bytes");
 
 struct alignas(16) Geom { float w[12]; };
 struct alignas(16) Shade { float n[9]; uint32_t mat; uint32_t pad[2]; };

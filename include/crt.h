@@ -17,7 +17,7 @@ extern "C" {
 #endif
 
 #define CRT_MAX_LIGHTS 8
-#define CRT_MAX_PRIMS ((1 << 24) - 64)
+#define CRT_MAX_PRIMS ((1 << 25) - 64)
 
 typedef enum crt_status {
     CRT_OK = 0,
