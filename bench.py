@@ -205,7 +205,7 @@ def main():
                 "workload": f"configs[3]: synthetic {a.tris}-triangle random soup (seed 1), {a.width}x{a.height}, "
                             f"bounces={a.bounces} (primary + {a.bounces - 1} reflections), 2 directional lights, "
                             f"spp={a.spp}; frame tiles 32x32 sharded over {world} GPU(s)",
-                "bvh": "wide4-sah" if a.bvh == 0 else "reference-topology",
+                "bvh": "wide8-sah-compressed" if a.bvh == 0 else "reference-topology",
                 "rays_per_frame": {"primary": int(rays[0]), "shadow": int(rays[1]), "reflect": int(rays[2])},
                 "frame_ms_device_rank0": round(acc["ms_total"] / a.steps, 4),
                 "frame_ms_split_rank0": {"trace_nearest": round(acc["ms_trace_nearest"] / a.steps, 4),
@@ -222,11 +222,13 @@ def main():
                 "traffic": None,
                 "algorithmic_bytes_per_launch": int(per_launch_bytes), "avg_launch_ms": round(avg_ms, 4),
                 "launches_timed": acc["launches_trace_nearest"],
-                "per_ray": {"box_tests": round(cst["box_tests"] / max(1, n_near), 2),
+                "per_ray": {"node_visits": round(cst["node_visits"] / max(1, n_near), 2),
+                            "box_tests": round(cst["box_tests"] / max(1, n_near), 2),
                             "tri_tests": round(cst["tri_tests"] / max(1, n_near), 2),
                             "bytes": round(bytes_near / max(1, n_near), 1)},
                 "shadow_kernel": {"kernel": "k_trace<SHADOW>", "achieved": round(sh_achieved, 2),
                                   "frac": round(sh_achieved / HBM_PEAK_GBS, 5), "avg_launch_ms": round(sh_avg_ms, 4),
+                                  "per_ray_node_visits": round(cst["node_visits_shadow"] / max(1, cst["rays_shadow"]), 2),
                                   "per_ray_box_tests": round(cst["box_tests_shadow"] / max(1, cst["rays_shadow"]), 2),
                                   "per_ray_tri_tests": round(cst["tri_tests_shadow"] / max(1, cst["rays_shadow"]), 2)},
             },

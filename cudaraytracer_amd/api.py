@@ -53,7 +53,8 @@ class Stats(C.Structure):
                 ("ms_trace_nearest", C.c_double), ("ms_trace_shadow", C.c_double),
                 ("launches_trace_nearest", C.c_int32), ("launches_trace_shadow", C.c_int32),
                 ("nodes", C.c_int32), ("prims", C.c_int32), ("depth", C.c_int32), ("leaves", C.c_int32),
-                ("ms_build_host", C.c_double), ("ms_refit", C.c_double), ("scene_bytes", C.c_uint64)]
+                ("ms_build_host", C.c_double), ("ms_refit", C.c_double), ("scene_bytes", C.c_uint64),
+                ("node_visits", C.c_uint64), ("node_visits_shadow", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -197,8 +198,8 @@ def host_bvh(prims, mode=0):
     if rc < 0:
         raise CrtError(rc, "crt_host_bvh")
     root = np.zeros(6, np.float32)
-    boxes = np.zeros((nn.value, 4, 6), np.float32)
-    links = np.zeros((nn.value, 4), np.uint32)
+    boxes = np.zeros((nn.value, 8, 6), np.float32)
+    links = np.zeros((nn.value, 8), np.uint32)
     parents = np.zeros((nn.value, 2), np.uint32)
     s2s = np.zeros(n, np.uint32)
     rank = np.zeros(n, np.uint32)
@@ -289,8 +290,8 @@ class Context:
         n = C.c_int32(0)
         self._ck(lib.crt_bvh_dump(self.h, C.byref(n), None, None, None, 0))
         root = np.zeros(6, np.float32)
-        boxes = np.zeros((n.value, 4, 6), np.float32)
-        links = np.zeros((n.value, 4), np.uint32)
+        boxes = np.zeros((n.value, 8, 6), np.float32)
+        links = np.zeros((n.value, 8), np.uint32)
         self._ck(lib.crt_bvh_dump(self.h, C.byref(n), _ptr(root), _ptr(boxes), _ptr(links), n.value))
         return root, boxes, links
 

@@ -127,14 +127,17 @@ inline void prim_bounds(const crt_prim& o, float lo[3], float hi[3]) {
     }
 }
 
-void node4_clear(Node4& n) {
-    for (int k = 0; k < 4; k++) {
+template <class N>
+void node_clear(N& n) {
+    std::memset(&n, 0, sizeof n);
+    for (int k = 0; k < N::W; k++) {
         n.lox[k] = n.loy[k] = n.loz[k] = kFmax;
         n.hix[k] = n.hiy[k] = n.hiz[k] = -kFmax;
         n.child[k] = kChildEmpty;
     }
     n.parent = kChildEmpty; n.parent_slot = 0; n.n_internal = 0; n.pad = 0;
 }
+void node4_clear(Node4& n) { node_clear(n); }
 
 }  // namespace
 
@@ -188,7 +191,7 @@ static void ranks_from(const RefTree& t, int n, std::vector<uint32_t>& rank) {
  * kChildEmpty but keep their (inverted) box so that dumps compare with the reference's. */
 int pack_reference(const crt_prim* prims, int n, const RefTree& t, HostBVH& out) {
     (void)prims;
-    out.nodes.clear(); out.mode = CRT_BVH_REFERENCE; out.depth = t.depth + 1; out.leaves = (int)t.leafs.size();
+    out.nodes.clear(); out.nodes8.clear(); out.mode = CRT_BVH_REFERENCE; out.depth = t.depth + 1; out.leaves = (int)t.leafs.size();
     out.slot_to_scene.resize(n);
     for (int i = 0; i < n; i++) out.slot_to_scene[i] = (uint32_t)t.order[i];   /* slot == reference rank */
     ranks_from(t, n, out.rank_of_scene);
@@ -231,7 +234,7 @@ int pack_reference(const crt_prim* prims, int n, const RefTree& t, HostBVH& out)
 }
 
 /* ------------------------------------------------------------------------------------------
- * Wide builder: binned SAH (16 bins, 3 axes) binary tree, then collapse to 4 children per node.
+ * Wide builder: binned SAH (16 bins, 3 axes) binary tree, then collapse to 8 children per node.
  * ------------------------------------------------------------------------------------------ */
 namespace {
 
@@ -331,7 +334,7 @@ struct WideBuilder {
 }  // namespace
 
 int build_wide(const crt_prim* prims, int n, const RefTree* ref, HostBVH& out) {
-    out.nodes.clear(); out.mode = CRT_BVH_WIDE; out.depth = 0; out.leaves = 0;
+    out.nodes.clear(); out.nodes8.clear(); out.mode = CRT_BVH_WIDE; out.depth = 0; out.leaves = 0;
     out.slot_to_scene.clear(); out.slot_to_scene.reserve(n);
     if (ref) ranks_from(*ref, n, out.rank_of_scene);
     else { out.rank_of_scene.resize(n); for (int i = 0; i < n; i++) out.rank_of_scene[i] = (uint32_t)i; }
@@ -346,26 +349,26 @@ int build_wide(const crt_prim* prims, int n, const RefTree* ref, HostBVH& out) {
     wb.nodes.reserve((size_t)n);
     if (n > 0) wb.build(0, n);
 
-    Node4 rootn; node4_clear(rootn);
-    out.nodes.push_back(rootn);
+    Node8 rootn; node_clear(rootn);
+    out.nodes8.push_back(rootn);
     AABB rb; rb.reset();
     if (n > 0) rb = wb.nodes[0].box;
     out.root_box[0] = rb.lo[0]; out.root_box[1] = rb.hi[0]; out.root_box[2] = rb.lo[1];
     out.root_box[3] = rb.hi[1]; out.root_box[4] = rb.lo[2]; out.root_box[5] = rb.hi[2];
     if (n == 0) return 0;
 
-    /* collapse: (binary node, packed index, depth); slots are assigned in DFS leaf order */
+    /* collapse: (binary node, packed index, depth) */
     struct Item { int b; int p; int depth; };
     std::vector<Item> stack;
     stack.push_back({0, 0, 1});
     while (!stack.empty()) {
         Item it = stack.back(); stack.pop_back();
         if (it.depth > out.depth) out.depth = it.depth;
-        int kids[4]; int nk = 0;
+        int kids[8]; int nk = 0;
         const BNode& bn = wb.nodes[it.b];
         if (bn.left < 0) kids[nk++] = it.b;
         else { kids[nk++] = bn.left; kids[nk++] = bn.right; }
-        while (nk < 4) {
+        while (nk < 8) {            /* open the child with the largest surface area */
             int best = -1; float bestA = -1.f;
             for (int k = 0; k < nk; k++) {
                 const BNode& c = wb.nodes[kids[k]];
@@ -378,51 +381,67 @@ int build_wide(const crt_prim* prims, int n, const RefTree* ref, HostBVH& out) {
             kids[best] = wb.nodes[c].left;
             kids[nk++] = wb.nodes[c].right;
         }
-        /* children pushed in reverse so that child 0 is expanded first (DFS slot order) */
-        int childPacked[4];
-        for (int k = 0; k < nk; k++) {
-            const BNode& c = wb.nodes[kids[k]];
-            Node4& nd = out.nodes[it.p];
-            nd.lox[k] = c.box.lo[0]; nd.loy[k] = c.box.lo[1]; nd.loz[k] = c.box.lo[2];
-            nd.hix[k] = c.box.hi[0]; nd.hiy[k] = c.box.hi[1]; nd.hiz[k] = c.box.hi[2];
-            if (c.left < 0) { childPacked[k] = -1; }
-            else {
-                childPacked[k] = (int)out.nodes.size();
-                Node4 nn; node4_clear(nn); nn.parent = (uint32_t)it.p; nn.parent_slot = (uint32_t)k;
-                out.nodes.push_back(nn);
-                out.nodes[it.p].child[k] = (uint32_t)childPacked[k];
-                out.nodes[it.p].n_internal++;
+        /* octant slots: slot bit 4/2/1 = child centre on the +x/+y/+z side of the node centre.
+         * Greedy assignment of (child, slot) pairs by the projection of the child's offset on the
+         * slot's diagonal; the traversal visits hit children in descending (slot ^ ray octant). */
+        float ctr[3];
+        for (int a = 0; a < 3; a++) ctr[a] = 0.5f * (bn.box.lo[a] + bn.box.hi[a]);
+        int slot_of_kid[8]; bool slot_used[8] = {false, false, false, false, false, false, false, false};
+        bool kid_done[8] = {false, false, false, false, false, false, false, false};
+        for (int round = 0; round < nk; round++) {
+            int bi = -1, bs = -1; float bc = -kFmax;
+            for (int i = 0; i < nk; i++) {
+                if (kid_done[i]) continue;
+                const AABB& cb = wb.nodes[kids[i]].box;
+                float v[3];
+                for (int a = 0; a < 3; a++) v[a] = 0.5f * (cb.lo[a] + cb.hi[a]) - ctr[a];
+                for (int s = 0; s < 8; s++) {
+                    if (slot_used[s]) continue;
+                    const float c = ((s & 4) ? v[0] : -v[0]) + ((s & 2) ? v[1] : -v[1]) + ((s & 1) ? v[2] : -v[2]);
+                    if (c > bc) { bc = c; bi = i; bs = s; }
+                }
+            }
+            kid_done[bi] = true; slot_used[bs] = true; slot_of_kid[bi] = bs;
+        }
+        int kid_at[8];
+        for (int s = 0; s < 8; s++) kid_at[s] = -1;
+        for (int i = 0; i < nk; i++) kid_at[slot_of_kid[i]] = kids[i];
+
+        /* internal children become consecutive nodes, leaf primitives one consecutive slot range, both in slot order */
+        int childPacked[8];
+        for (int s = 0; s < 8; s++) {
+            childPacked[s] = -1;
+            if (kid_at[s] < 0) continue;
+            const BNode& c = wb.nodes[kid_at[s]];
+            Node8& nd = out.nodes8[it.p];
+            nd.lox[s] = c.box.lo[0]; nd.loy[s] = c.box.lo[1]; nd.loz[s] = c.box.lo[2];
+            nd.hix[s] = c.box.hi[0]; nd.hiy[s] = c.box.hi[1]; nd.hiz[s] = c.box.hi[2];
+            if (c.left >= 0) {
+                childPacked[s] = (int)out.nodes8.size();
+                Node8 nn; node_clear(nn); nn.parent = (uint32_t)it.p; nn.parent_slot = (uint32_t)s;
+                out.nodes8.push_back(nn);
+                out.nodes8[it.p].child[s] = (uint32_t)childPacked[s];
+                out.nodes8[it.p].n_internal++;
             }
         }
-        for (int k = 0; k < nk; k++) {
-            const BNode& c = wb.nodes[kids[k]];
+        uint32_t node_prims = 0;
+        for (int s = 0; s < 8; s++) {
+            if (kid_at[s] < 0) continue;
+            const BNode& c = wb.nodes[kid_at[s]];
             if (c.left < 0) {
+                if (c.count > kWide8LeafMax) return CRT_ERR_BUILD;
                 uint32_t start = (uint32_t)out.slot_to_scene.size();
                 for (int i = c.first; i < c.first + c.count; i++) out.slot_to_scene.push_back((uint32_t)refs[i].idx);
-                out.nodes[it.p].child[k] = make_leaf(start, (uint32_t)c.count);
+                out.nodes8[it.p].child[s] = make_leaf(start, (uint32_t)c.count);
                 out.leaves++;
+                node_prims += (uint32_t)c.count;
             }
         }
-        for (int k = nk - 1; k >= 0; k--)
-            if (childPacked[k] >= 0) stack.push_back({kids[k], childPacked[k], it.depth + 1});
+        if (node_prims > 32u) return CRT_ERR_BUILD;       /* QNode8::meta holds a 5-bit offset */
+        for (int s = 7; s >= 0; s--)
+            if (childPacked[s] >= 0) stack.push_back({kid_at[s], childPacked[s], it.depth + 1});
     }
-    /* the quantised traversal node (layout.h QNode) derives child links from two base indices:
-     * internal children must be consecutive nodes and leaf children consecutive slots, in child order */
-    for (const Node4& nd : out.nodes) {
-        uint32_t next_node = 0, next_slot = 0; bool hn = false, hl = false;
-        for (int k = 0; k < 4; k++) {
-            const uint32_t l = nd.child[k];
-            if (l == kChildEmpty) continue;
-            if (l & kLeafFlag) {
-                const uint32_t start = l & kLeafStartMask, cnt = ((l >> kLeafCountShift) & 63u) + 1u;
-                if ((hl && start != next_slot) || cnt > (uint32_t)kWideLeaf) return CRT_ERR_BUILD;
-                hl = true; next_slot = start + cnt;
-            } else {
-                if (hn && l != next_node) return CRT_ERR_BUILD;
-                hn = true; next_node = l + 1;
-            }
-        }
-    }
+    if (out.nodes8.size() >= (1u << 24)) return CRT_ERR_BUILD;   /* QNode8::base_vmask keeps 24 bits for the index */
     return 0;
 }
 

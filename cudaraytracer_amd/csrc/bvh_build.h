@@ -1,13 +1,14 @@
 /* bvh_build.h -- host BVH construction.
  *
- * Two builders feed the same packed 4-wide node format (layout.h):
+ * Two builders feed the packed node formats of layout.h:
  *   - build_reference(): the reference's topology -- top-down split on the node's longest axis at
  *     the MEAN of the child centroids, stable partition `centroid <= midpoint -> left`, leaf at
  *     <= 64 primitives (main.cu:33-136 newBuild, bvh.cu:12-273 constructTree).  It also yields
  *     the reference's leaf order, which defines the tie-break rank of every primitive.
- *   - build_wide(): binned-SAH binary tree over the same primitives, collapsed to 4-wide nodes with
- *     <= 4 primitives per leaf.  This is what the render kernels use by default; nearest hits are
- *     independent of tree shape once ties resolve by reference rank.
+ *   - build_wide(): binned-SAH binary tree over the same primitives, collapsed to 8-wide nodes
+ *     (Node8) with <= 4 primitives per leaf and children placed in octant slots.  This is what the
+ *     render kernels use by default; nearest hits are independent of tree shape once ties resolve
+ *     by reference rank.
  */
 #ifndef CRT_BVH_BUILD_H
 #define CRT_BVH_BUILD_H
@@ -35,7 +36,9 @@ struct RefTree {
 };
 
 struct HostBVH {
-    std::vector<Node4> nodes;
+    std::vector<Node4> nodes;              /* CRT_BVH_REFERENCE */
+    std::vector<Node8> nodes8;             /* CRT_BVH_WIDE */
+    size_t node_count() const { return mode == CRT_BVH_WIDE ? nodes8.size() : nodes.size(); }
     std::vector<uint32_t> slot_to_scene;
     std::vector<uint32_t> rank_of_scene;   /* reference leaf-order position of each scene index */
     float root_box[6];

@@ -92,8 +92,8 @@ Node* constructTree(std::vector<SceneObject*>& objects, Node*& currentNode, std:
     int32_t nn = 0, depth = 0;
     if (crt_host_bvh(prims.data(), n, CRT_BVH_REFERENCE, &nn, &depth, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0) != CRT_OK)
         return currentNode;
-    std::vector<float> boxes((size_t)nn * 24), root(6);
-    std::vector<uint32_t> links((size_t)nn * 4), parents((size_t)nn * 2), s2s(n), rank(n);
+    std::vector<float> boxes((size_t)nn * CRT_BVH_DUMP_WIDTH * 6), root(6);
+    std::vector<uint32_t> links((size_t)nn * CRT_BVH_DUMP_WIDTH), parents((size_t)nn * 2), s2s(n), rank(n);
     crt_host_bvh(prims.data(), n, CRT_BVH_REFERENCE, &nn, &depth, root.data(), boxes.data(), links.data(), parents.data(),
                  s2s.data(), rank.data(), nn);
     free_nodes(currentNode);
@@ -124,11 +124,11 @@ Node* constructTree(std::vector<SceneObject*>& objects, Node*& currentNode, std:
         for (int k = 0; k < 2; k++) {
             kids[k] = new Node(); g_nodes.push_back(kids[k]);
             kids[k]->parent = host; kids[k]->nodeNum = counter++;
-            set_box(kids[k], &boxes[((size_t)packed * 4 + k) * 6]);
+            set_box(kids[k], &boxes[((size_t)packed * CRT_BVH_DUMP_WIDTH + k) * 6]);
         }
         host->left = kids[0]; host->right = kids[1];
         for (int k = 0; k < 2; k++) {
-            const uint32_t link = links[(size_t)packed * 4 + k];
+            const uint32_t link = links[(size_t)packed * CRT_BVH_DUMP_WIDTH + k];
             if (link == 0xffffffffu || (link & 0x80000000u)) make_leaf(kids[k], link);
             else expand(kids[k], link);
         }

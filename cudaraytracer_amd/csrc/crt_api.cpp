@@ -40,7 +40,6 @@ struct crt_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     bool counting = false, capture = false;
-    bool use_qnodes = true;      /* CRT_NO_QNODES=1 traverses the exact 128-byte nodes instead (A/B experiments) */
 
     std::vector<crt_prim> prims;
     std::vector<uint32_t> matid;
@@ -113,7 +112,7 @@ SceneView view_of(const crt_ctx* c) {
     SceneView v{};
     const char* b = (const char*)c->d_blob;
     v.nodes = (const Node4*)(b + c->hdr.off_nodes);
-    v.qnodes = (const QNode*)(b + c->hdr.off_qnodes);
+    v.qnodes = (const QNode8*)(b + c->hdr.off_qnodes);
     v.geom = (const Geom*)(b + c->hdr.off_geom);
     v.shade = (const Shade*)(b + c->hdr.off_shade);
     v.rank = (const uint32_t*)(b + c->hdr.off_rank);
@@ -160,8 +159,9 @@ int upload_prims(crt_ctx* c) {
 
 void layout_blob(BlobHeader& h) {
     size_t off = align_up(sizeof(BlobHeader), 256);
-    h.off_nodes = off; off = align_up(off + (size_t)h.nnodes * sizeof(Node4), 256);
-    h.off_qnodes = off; off = align_up(off + (size_t)h.nnodes * sizeof(QNode), 256);
+    const bool wide = h.mode == CRT_BVH_WIDE;
+    h.off_nodes = off; off = align_up(off + (size_t)h.nnodes * (wide ? sizeof(Node8) : sizeof(Node4)), 256);
+    h.off_qnodes = off; off = align_up(off + (wide ? (size_t)h.nnodes * sizeof(QNode8) : 0), 256);
     h.off_geom = off; off = align_up(off + (size_t)h.nprims * sizeof(Geom), 256);
     h.off_shade = off; off = align_up(off + (size_t)h.nprims * sizeof(Shade), 256);
     h.off_rank = off; off = align_up(off + (size_t)h.nprims * 4, 256);
@@ -172,10 +172,13 @@ void layout_blob(BlobHeader& h) {
 }
 
 int size_overflow(crt_ctx* c) {
-    /* worst-case stack need: 3 pushes per 4-wide level (+1), 1 per level for the 2-wide reference topology */
-    const int bound = (c->hdr.mode == CRT_BVH_WIDE ? 3 : 1) * (int)c->hdr.depth + 2;
-    c->ovf_depth = bound > kStackDepth ? bound - kStackDepth : 0;
-    const size_t need = (size_t)c->grid_blocks * kTraceBlock * (size_t)c->ovf_depth;
+    /* worst-case stack need: one entry per level, for the 8-wide tree (one 64-bit group entry per
+     * visited node) as for the 2-wide reference topology (one 32-bit link) */
+    const bool wide = c->hdr.mode == CRT_BVH_WIDE;
+    const int bound = (int)c->hdr.depth + 2;
+    const int in_lds = wide ? kStackDepth8 : kStackDepth;
+    c->ovf_depth = bound > in_lds ? bound - in_lds : 0;
+    const size_t need = (size_t)c->grid_blocks * kTraceBlock * (size_t)c->ovf_depth * (wide ? 2 : 1);
     if (need > c->ovf_cap || !c->d_ovf) {
         if (c->d_ovf) HIPCHECK(c, hipFree(c->d_ovf));
         c->d_ovf = nullptr;
@@ -262,12 +265,32 @@ int ensure_frame(crt_ctx* c, size_t cap, size_t npix, int bounces, int nlights, 
 int check_status(crt_ctx* c) {
     uint32_t st = 0;
     HIPCHECK(c, hipMemcpy(&st, c->d_status, 4, hipMemcpyDeviceToHost));
-    if (st & 1u) {
+    if (st) {
         uint32_t z = 0;
         hipMemcpy(c->d_status, &z, 4, hipMemcpyHostToDevice);
+        if (st & 2u) return fail(c, CRT_ERR_BUILD, "wide tree does not fit the compressed node format");
         return fail(c, CRT_ERR_STATE, "traversal stack overflow: tree deeper than the sized overflow area");
     }
     return CRT_OK;
+}
+
+/* dumps always carry CRT_BVH_DUMP_WIDTH (8) child entries per node; slots a format does not have are empty */
+template <class N>
+void export_nodes(const std::vector<N>& nodes, float* child_boxes, uint32_t* child_links, uint32_t* parents) {
+    for (size_t i = 0; i < nodes.size(); i++) {
+        for (int k = 0; k < CRT_BVH_DUMP_WIDTH; k++) {
+            float* o = child_boxes + (i * CRT_BVH_DUMP_WIDTH + k) * 6;
+            if (k < N::W) {
+                o[0] = nodes[i].lox[k]; o[1] = nodes[i].hix[k]; o[2] = nodes[i].loy[k];
+                o[3] = nodes[i].hiy[k]; o[4] = nodes[i].loz[k]; o[5] = nodes[i].hiz[k];
+                child_links[i * CRT_BVH_DUMP_WIDTH + k] = nodes[i].child[k];
+            } else {
+                o[0] = o[2] = o[4] = 3.402823466e+38f; o[1] = o[3] = o[5] = -3.402823466e+38f;
+                child_links[i * CRT_BVH_DUMP_WIDTH + k] = kChildEmpty;
+            }
+        }
+        if (parents) { parents[2 * i] = nodes[i].parent; parents[2 * i + 1] = nodes[i].parent_slot; }
+    }
 }
 
 }  // namespace
@@ -283,15 +306,14 @@ crt_ctx* crt_create(int device, int* err) {
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void**)&c->d_status, 4) != hipSuccess ||
-        hipMalloc((void**)&c->d_testctr, 6 * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc((void**)&c->d_testctr, 8 * sizeof(unsigned long long)) != hipSuccess) {
         if (err) *err = CRT_ERR_HIP;
         delete c;
         return nullptr;
     }
     hipMemset(c->d_status, 0, 4);
-    hipMemset(c->d_testctr, 0, 6 * sizeof(unsigned long long));
+    hipMemset(c->d_testctr, 0, 8 * sizeof(unsigned long long));
     c->grid_blocks = trace_grid_blocks(device);
-    c->use_qnodes = getenv("CRT_NO_QNODES") == nullptr;
     if (err) *err = CRT_OK;
     return c;
 }
@@ -386,7 +408,7 @@ int crt_bvh_build(crt_ctx* c, int mode) {
 
     BlobHeader h{};
     h.magic = kBlobMagic; h.version = kBlobVersion;
-    h.nprims = (uint32_t)n; h.nnodes = (uint32_t)c->bvh.nodes.size(); h.nmats = (uint32_t)c->mats.size();
+    h.nprims = (uint32_t)n; h.nnodes = (uint32_t)c->bvh.node_count(); h.nmats = (uint32_t)c->mats.size();
     h.depth = (uint32_t)c->bvh.depth; h.mode = (uint32_t)mode;
     memcpy(h.root_box, c->bvh.root_box, sizeof h.root_box);
     layout_blob(h);
@@ -405,7 +427,10 @@ int crt_bvh_build(crt_ctx* c, int mode) {
         slot_of[si] = (uint32_t)s;
     }
     HIPCHECK(c, hipMemcpyAsync(b, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(b + h.off_nodes, c->bvh.nodes.data(), (size_t)h.nnodes * sizeof(Node4), hipMemcpyHostToDevice, c->stream));
+    if (mode == CRT_BVH_WIDE)
+        HIPCHECK(c, hipMemcpyAsync(b + h.off_nodes, c->bvh.nodes8.data(), (size_t)h.nnodes * sizeof(Node8), hipMemcpyHostToDevice, c->stream));
+    else
+        HIPCHECK(c, hipMemcpyAsync(b + h.off_nodes, c->bvh.nodes.data(), (size_t)h.nnodes * sizeof(Node4), hipMemcpyHostToDevice, c->stream));
     if (n) {
         HIPCHECK(c, hipMemcpyAsync(b + h.off_rank, rank_slot.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHECK(c, hipMemcpyAsync(b + h.off_sidx, c->bvh.slot_to_scene.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
@@ -414,9 +439,11 @@ int crt_bvh_build(crt_ctx* c, int mode) {
     if (h.nmats) HIPCHECK(c, hipMemcpyAsync(b + h.off_mats, c->mats.data(), (size_t)h.nmats * sizeof(Material), hipMemcpyHostToDevice, c->stream));
     launch_pack_prims(c->d_prims, c->d_matid, (const uint32_t*)(b + h.off_slot_of), (uint32_t)n, (Geom*)(b + h.off_geom),
                       (Shade*)(b + h.off_shade), c->stream);
-    if (mode == CRT_BVH_WIDE) launch_quantize((const Node4*)(b + h.off_nodes), h.nnodes, (QNode*)(b + h.off_qnodes), c->stream);
+    if (mode == CRT_BVH_WIDE) launch_quantize((const Node8*)(b + h.off_nodes), h.nnodes, (QNode8*)(b + h.off_qnodes), c->d_status, c->stream);
     HIPCHECK(c, hipGetLastError());
     HIPCHECK(c, hipStreamSynchronize(c->stream));      /* host staging vectors go out of scope */
+    rc = check_status(c);
+    if (rc) return rc;
     rc = ensure(c, c->d_arrive, c->arrive_cap, (size_t)h.nnodes + 1);
     if (rc) return rc;
     scene_abs_from_box(c);
@@ -436,17 +463,21 @@ int crt_bvh_refit(crt_ctx* c, int grow_only) {
     hipEvent_t e0 = next_event(c), e1 = next_event(c);
     c->evused -= 2;
     HIPCHECK(c, hipEventRecord(e0, c->stream));
-    launch_refit((Node4*)(b + c->hdr.off_nodes), c->hdr.nnodes, (const Geom*)(b + c->hdr.off_geom), c->d_arrive,
-                 (float*)(b + offsetof(BlobHeader, root_box)), grow_only ? 1 : 0, c->stream);
-    if (c->hdr.mode == CRT_BVH_WIDE)
-        launch_quantize((const Node4*)(b + c->hdr.off_nodes), c->hdr.nnodes, (QNode*)(b + c->hdr.off_qnodes), c->stream);
+    if (c->hdr.mode == CRT_BVH_WIDE) {
+        launch_refit8((Node8*)(b + c->hdr.off_nodes), c->hdr.nnodes, (const Geom*)(b + c->hdr.off_geom), c->d_arrive,
+                      (float*)(b + offsetof(BlobHeader, root_box)), grow_only ? 1 : 0, c->stream);
+        launch_quantize((const Node8*)(b + c->hdr.off_nodes), c->hdr.nnodes, (QNode8*)(b + c->hdr.off_qnodes), c->d_status, c->stream);
+    } else {
+        launch_refit((Node4*)(b + c->hdr.off_nodes), c->hdr.nnodes, (const Geom*)(b + c->hdr.off_geom), c->d_arrive,
+                     (float*)(b + offsetof(BlobHeader, root_box)), grow_only ? 1 : 0, c->stream);
+    }
     HIPCHECK(c, hipGetLastError());
     HIPCHECK(c, hipEventRecord(e1, c->stream));
     HIPCHECK(c, hipMemcpyAsync(c->hdr.root_box, b + offsetof(BlobHeader, root_box), sizeof c->hdr.root_box, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     float ms = 0; hipEventElapsedTime(&ms, e0, e1); c->stats.ms_refit = ms;
     scene_abs_from_box(c);
-    return CRT_OK;
+    return check_status(c);
 }
 
 int crt_bvh_free(crt_ctx* c) {
@@ -474,18 +505,18 @@ int crt_bvh_dump(crt_ctx* c, int32_t* nnodes, float* root_box6, float* child_box
     *nnodes = (int32_t)c->hdr.nnodes;
     if (!child_boxes || !child_links) return CRT_OK;
     if (cap_nodes < (int)c->hdr.nnodes) return fail(c, CRT_ERR_ARG, "crt_bvh_dump: buffer too small");
-    std::vector<Node4> nodes(c->hdr.nnodes);
     const char* b = (const char*)c->d_blob;
     HIPCHECK(c, hipStreamSynchronize(c->stream));
-    HIPCHECK(c, hipMemcpy(nodes.data(), b + c->hdr.off_nodes, nodes.size() * sizeof(Node4), hipMemcpyDeviceToHost));
     if (root_box6) HIPCHECK(c, hipMemcpy(root_box6, b + offsetof(BlobHeader, root_box), 24, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < nodes.size(); i++)
-        for (int k = 0; k < 4; k++) {
-            float* o = child_boxes + (i * 4 + k) * 6;
-            o[0] = nodes[i].lox[k]; o[1] = nodes[i].hix[k]; o[2] = nodes[i].loy[k];
-            o[3] = nodes[i].hiy[k]; o[4] = nodes[i].loz[k]; o[5] = nodes[i].hiz[k];
-            child_links[i * 4 + k] = nodes[i].child[k];
-        }
+    if (c->hdr.mode == CRT_BVH_WIDE) {
+        std::vector<Node8> nodes(c->hdr.nnodes);
+        HIPCHECK(c, hipMemcpy(nodes.data(), b + c->hdr.off_nodes, nodes.size() * sizeof(Node8), hipMemcpyDeviceToHost));
+        export_nodes(nodes, child_boxes, child_links, nullptr);
+    } else {
+        std::vector<Node4> nodes(c->hdr.nnodes);
+        HIPCHECK(c, hipMemcpy(nodes.data(), b + c->hdr.off_nodes, nodes.size() * sizeof(Node4), hipMemcpyDeviceToHost));
+        export_nodes(nodes, child_boxes, child_links, nullptr);
+    }
     return CRT_OK;
 }
 
@@ -564,7 +595,7 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
     if (rc) return rc;
     c->h_ctr.assign((size_t)spp * kCtrStride, 0);
     HIPCHECK(c, hipMemsetAsync(c->d_ctr, 0, (size_t)spp * kCtrStride * 4, c->stream));
-    if (c->counting) HIPCHECK(c, hipMemsetAsync(c->d_testctr, 0, 6 * sizeof(unsigned long long), c->stream));
+    if (c->counting) HIPCHECK(c, hipMemsetAsync(c->d_testctr, 0, 8 * sizeof(unsigned long long), c->stream));
     if (c->capture) {
         HIPCHECK(c, hipMemsetD32Async((hipDeviceptr_t)c->cap_ids, -9, (size_t)p->bounces * npix, c->stream));
         HIPCHECK(c, hipMemsetD32Async((hipDeviceptr_t)c->cap_ts, 0, (size_t)p->bounces * npix, c->stream));
@@ -594,15 +625,15 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
             ta.sv = sv; ta.rayO = fb.rayO; ta.rayD = fb.rayD; ta.count = ctr + b; ta.next = ctr + kCtrFetch0 + (2 * b) * 8 * kFetchStride;
             ta.hitSlot = c->hitSlot; ta.hitT = c->hitT; ta.shflag = nullptr; ta.scene_abs = c->scene_abs;
             ta.ovf = c->d_ovf; ta.ovf_depth = c->ovf_depth; ta.counters = c->d_testctr; ta.status = c->d_status;
-            launch_trace(ta, c->lights, TRACE_NEAREST, c->counting, c->use_qnodes && c->hdr.mode == CRT_BVH_WIDE, c->grid_blocks, c->stream);
+            launch_trace(ta, c->lights, TRACE_NEAREST, c->counting, c->hdr.mode == CRT_BVH_WIDE, c->grid_blocks, c->stream);
             mark(c, EV_TRACE_N);
             launch_shade(fp, fb, sv, c->lights, ctr + b, ctr + b + 1, ctr + 16 + b, c->stream);
             mark(c, EV_SHADE);
             if (c->lights.n > 0) {
                 TraceArgs ts = ta;
                 ts.rayO = c->shO; ts.rayD = c->shD; ts.count = ctr + 16 + b; ts.next = ctr + kCtrFetch0 + (2 * b + 1) * 8 * kFetchStride;
-                ts.hitSlot = nullptr; ts.hitT = nullptr; ts.shflag = c->shflag; ts.counters = c->d_testctr + 3;
-                launch_trace(ts, c->lights, TRACE_SHADOW, c->counting, c->use_qnodes && c->hdr.mode == CRT_BVH_WIDE, c->grid_blocks, c->stream);
+                ts.hitSlot = nullptr; ts.hitT = nullptr; ts.shflag = c->shflag; ts.counters = c->d_testctr + 4;
+                launch_trace(ts, c->lights, TRACE_SHADOW, c->counting, c->hdr.mode == CRT_BVH_WIDE, c->grid_blocks, c->stream);
                 mark(c, EV_TRACE_S);
             }
             launch_resolve(fb, c->lights, ctr + b, c->stream);
@@ -649,10 +680,11 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
     hipEventElapsedTime(&tot, c->evpool[c->evlog.front().second], c->evpool[c->evlog.back().second]);
     st.ms_total = tot;
     if (c->counting) {
-        unsigned long long t[6];
+        unsigned long long t[8];
         HIPCHECK(c, hipMemcpy(t, c->d_testctr, sizeof t, hipMemcpyDeviceToHost));
         st.box_tests = t[0]; st.tri_tests = t[1]; st.sph_tests = t[2];
-        st.box_tests_shadow = t[3]; st.tri_tests_shadow = t[4]; st.sph_tests_shadow = t[5];
+        st.node_visits = t[3];
+        st.box_tests_shadow = t[4]; st.tri_tests_shadow = t[5]; st.sph_tests_shadow = t[6]; st.node_visits_shadow = t[7];
     }
     c->last_w = p->width; c->last_h = p->height; c->last_bounces = p->bounces;
     return CRT_OK;
@@ -709,10 +741,14 @@ static int trace_hook(crt_ctx* c, const float* org_dir, int n, int32_t* prim_out
         ta.sv = view_of(c); ta.rayO = d_o; ta.rayD = d_d; ta.count = d_cnt; ta.next = d_cnt + 64;
         ta.hitSlot = d_slot; ta.hitT = d_t; ta.shflag = d_flag; ta.scene_abs = c->scene_abs;
         ta.ovf = c->d_ovf; ta.ovf_depth = c->ovf_depth; ta.counters = c->d_testctr; ta.status = c->d_status;
-        if (c->counting) TH(hipMemsetAsync(c->d_testctr, 0, 6 * sizeof(unsigned long long), c->stream));
+        if (c->counting) TH(hipMemsetAsync(c->d_testctr, 0, 8 * sizeof(unsigned long long), c->stream));
         LightsParam dummy{}; dummy.n = 1;          /* light 0 directional: the Ray.cu:650-656 predicate */
-        launch_trace(ta, dummy, shadow_out ? TRACE_SHADOW : TRACE_NEAREST, c->counting, c->use_qnodes && c->hdr.mode == CRT_BVH_WIDE, c->grid_blocks, c->stream);
+        hipEvent_t e0 = next_event(c), e1 = next_event(c);
+        c->evused -= 2;
+        TH(hipEventRecord(e0, c->stream));
+        launch_trace(ta, dummy, shadow_out ? TRACE_SHADOW : TRACE_NEAREST, c->counting, c->hdr.mode == CRT_BVH_WIDE, c->grid_blocks, c->stream);
         TH(hipGetLastError());
+        TH(hipEventRecord(e1, c->stream));
         if (shadow_out) TH(hipMemcpyAsync(shadow_out, d_flag, (size_t)n, hipMemcpyDeviceToHost, c->stream));
         else {
             launch_slots_to_scene(d_slot, ta.sv.sidx, d_id, (uint32_t)n, c->stream);
@@ -720,10 +756,11 @@ static int trace_hook(crt_ctx* c, const float* org_dir, int n, int32_t* prim_out
             TH(hipMemcpyAsync(t_out, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
         }
         TH(hipStreamSynchronize(c->stream));
+        { float ms = 0; hipEventElapsedTime(&ms, e0, e1); c->stats.ms_trace = ms; }     /* the traversal launch alone */
         if (c->counting) {
-            unsigned long long t[3];
+            unsigned long long t[4];
             TH(hipMemcpy(t, c->d_testctr, sizeof t, hipMemcpyDeviceToHost));
-            c->stats.box_tests = t[0]; c->stats.tri_tests = t[1]; c->stats.sph_tests = t[2];
+            c->stats.box_tests = t[0]; c->stats.tri_tests = t[1]; c->stats.sph_tests = t[2]; c->stats.node_visits = t[3];
         }
     }
 done:
@@ -826,20 +863,13 @@ int crt_host_bvh(const crt_prim* prims, int n, int mode, int32_t* nnodes, int32_
     if (rc) return rc;
     rc = mode == CRT_BVH_WIDE ? build_wide(prims, n, &ref, bvh) : pack_reference(prims, n, ref, bvh);
     if (rc) return rc;
-    *nnodes = (int32_t)bvh.nodes.size();
+    *nnodes = (int32_t)bvh.node_count();
     if (depth) *depth = bvh.depth;
     if (root_box6) memcpy(root_box6, bvh.root_box, 24);
     if (!child_boxes || !child_links) return CRT_OK;
     if (cap_nodes < *nnodes) return CRT_ERR_ARG;
-    for (size_t i = 0; i < bvh.nodes.size(); i++) {
-        const Node4& nd = bvh.nodes[i];
-        for (int k = 0; k < 4; k++) {
-            float* o = child_boxes + (i * 4 + k) * 6;
-            o[0] = nd.lox[k]; o[1] = nd.hix[k]; o[2] = nd.loy[k]; o[3] = nd.hiy[k]; o[4] = nd.loz[k]; o[5] = nd.hiz[k];
-            child_links[i * 4 + k] = nd.child[k];
-        }
-        if (parents) { parents[2 * i] = nd.parent; parents[2 * i + 1] = nd.parent_slot; }
-    }
+    if (mode == CRT_BVH_WIDE) export_nodes(bvh.nodes8, child_boxes, child_links, parents);
+    else export_nodes(bvh.nodes, child_boxes, child_links, parents);
     if (slot_to_scene) memcpy(slot_to_scene, bvh.slot_to_scene.data(), (size_t)n * 4);
     if (rank_of_scene) memcpy(rank_of_scene, bvh.rank_of_scene.data(), (size_t)n * 4);
     return CRT_OK;

@@ -33,6 +33,20 @@ constexpr int kFetchChunk = CRT_FETCH_CHUNK;       /* rays a wave takes from the
 constexpr int kFetchStride = 64;       /* uint32 words between the 8 per-region fetch counters (256 B apart) */
 constexpr int kTraceBlock = 256;       /* 4 waves of 64 */
 constexpr int kStackDepth = CRT_STACK_DEPTH;        /* per-lane entries in LDS: stack[depth][lane], conflict-free per wave */
+#ifndef CRT_TRACE8_MIN_WAVES
+#define CRT_TRACE8_MIN_WAVES 0         /* 0: let the compiler choose; n: __launch_bounds__(256, n) waves per SIMD */
+#endif
+#ifndef CRT_STACK_DEPTH8
+#define CRT_STACK_DEPTH8 16
+#endif
+constexpr int kStackDepth8 = CRT_STACK_DEPTH8;      /* k_trace8: 64-bit entries, at most one per tree level */
+/* k_trace8 vote: a node step runs when n_node * PRIM_WEIGHT >= n_prim * NODE_WEIGHT */
+#ifndef CRT_VOTE8_PRIM_WEIGHT
+#define CRT_VOTE8_PRIM_WEIGHT 1
+#endif
+#ifndef CRT_VOTE8_NODE_WEIGHT
+#define CRT_VOTE8_NODE_WEIGHT 2
+#endif
 constexpr int kRefillMinIdle = CRT_REFILL_MIN_IDLE; /* a wave refills from the ray queue when >= this many lanes are idle */
 
 /* Camera basis of Ray.cu:684-689 plus the tile map of this rank. */
@@ -76,14 +90,14 @@ struct TraceArgs {
     int32_t* hitSlot; float* hitT;           /* NEAREST outputs */
     uint8_t* shflag;                         /* SHADOW output, indexed by the target in rayO.w */
     float scene_abs;             /* max |coordinate| of the root box: scales the slab-test pad */
-    uint32_t* ovf; int32_t ovf_depth;        /* per-thread stack overflow area in HBM */
-    unsigned long long* counters;            /* [0]=box [1]=tri [2]=sph tests, when counting */
-    uint32_t* status;            /* device error word: bit0 = stack overflow beyond ovf */
+    uint32_t* ovf; int32_t ovf_depth;        /* per-thread stack overflow area in HBM: ovf_depth entries of 4 B (k_trace) or 8 B (k_trace8) */
+    unsigned long long* counters;            /* [0]=box [1]=tri [2]=sph tests [3]=node visits, when counting */
+    uint32_t* status;            /* device error word: bit0 = stack overflow beyond ovf, bit1 = node not quantisable */
 };
 
 int trace_grid_blocks(int device);
-void launch_trace(const TraceArgs& a, const LightsParam& lights, int mode, bool counting, bool quantised, int blocks, hipStream_t s);
-void launch_quantize(const Node4* nodes, uint32_t nnodes, QNode* qnodes, hipStream_t s);
+void launch_trace(const TraceArgs& a, const LightsParam& lights, int mode, bool counting, bool wide, int blocks, hipStream_t s);
+void launch_quantize(const Node8* nodes, uint32_t nnodes, QNode8* qnodes, uint32_t* status, hipStream_t s);
 void launch_gen_primary(const FrameParams& fp, const FrameBuffers& fb, uint32_t* count, hipStream_t s);
 void launch_shade(const FrameParams& fp, const FrameBuffers& fb, const SceneView& sv, const LightsParam& lights,
                   const uint32_t* count, uint32_t* next_count, uint32_t* shadow_count, hipStream_t s);
@@ -94,6 +108,8 @@ void launch_pack_prims(const crt_prim* d_prims, const uint32_t* d_matid, const u
                        Geom* geom, Shade* shade, hipStream_t s);
 void launch_refit(Node4* nodes, uint32_t nnodes, const Geom* geom, uint32_t* arrive, float* root_box, int grow_only,
                   hipStream_t s);
+void launch_refit8(Node8* nodes, uint32_t nnodes, const Geom* geom, uint32_t* arrive, float* root_box, int grow_only,
+                   hipStream_t s);
 void launch_slots_to_scene(const int32_t* slots, const uint32_t* sidx, int32_t* out, uint32_t n, hipStream_t s);
 void launch_pack_rays(const float* org_dir, uint32_t n, float4* rayO, float4* rayD, hipStream_t s);
 void launch_tiles_copy(const FrameParams& fp, const uint32_t* tile_ids, int ntiles, const uint8_t* src, uint8_t* dst,

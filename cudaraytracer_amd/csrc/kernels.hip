@@ -96,7 +96,7 @@ CRT_DEV bool sphere_test(const GeomRec& g, const vec3& o, const vec3& d, float& 
 #else
 #define CRT_TRACE_BOUNDS __launch_bounds__(kTraceBlock)
 #endif
-template <int MODE, bool COUNT, bool QN>
+template <int MODE, bool COUNT>
 __global__ CRT_TRACE_BOUNDS void k_trace(TraceArgs A, LightsParam LP) {
     __shared__ uint32_t s_stack[kStackDepth + 1][kTraceBlock];   /* last row: write-only trash for the branch-free push */
     const int tid = threadIdx.x;
@@ -121,7 +121,7 @@ __global__ CRT_TRACE_BOUNDS void k_trace(TraceArgs A, LightsParam LP) {
     int sp = 0;
     int found = 0;          /* SHADOW: a hit with t > 1e-9 exists */
     int lightj = 0;
-    unsigned long long nbox = 0, ntri = 0, nsph = 0;
+    unsigned long long nbox = 0, ntri = 0, nsph = 0, nvis = 0;
 
     /* take the next item off the stack, or report that the ray is finished */
 #define POP_ITEM(FINISH)                                                                 \
@@ -204,13 +204,6 @@ __global__ CRT_TRACE_BOUNDS void k_trace(TraceArgs A, LightsParam LP) {
                             ax = (o.x + px) * ix; bx = (o.x - px) * ix;
                             ay = (o.y + py) * iy; by = (o.y - py) * iy;
                             az = (o.z + pz) * iz; bz = (o.z - pz) * iz;
-                            if (QN) {
-                                /* quantised path: planes are picked by the direction's sign instead of
-                                 * min/max per pair, so keep the offsets as (near, far) instead of (lo, hi) */
-                                if (ix < 0.f) { const float t_ = ax; ax = bx; bx = t_; }
-                                if (iy < 0.f) { const float t_ = ay; ay = by; by = t_; }
-                                if (iz < 0.f) { const float t_ = az; az = bz; bz = t_; }
-                            }
                             tbest = 1000000000.0f; best = -1; cur = 0; sp = 0; found = 0; lp = lend = 0;
                             active = true;
                         }
@@ -231,6 +224,7 @@ __global__ CRT_TRACE_BOUNDS void k_trace(TraceArgs A, LightsParam LP) {
                 if (want_node) {
                     float tn0, tn1, tn2, tn3;
                     uint32_t c0, c1, c2, c3;
+                    if (COUNT) nvis++;
 #define SLAB_T(K, X0, X1, Y0, Y1, Z0, Z1, C)                                                    \
     {                                                                                           \
         const float tn = fmaxf(fmaxf(fminf(X0, X1), fminf(Y0, Y1)), fmaxf(fminf(Z0, Z1), -1.0001e-4f)); \
@@ -238,42 +232,7 @@ __global__ CRT_TRACE_BOUNDS void k_trace(TraceArgs A, LightsParam LP) {
         K = ((C) != kChildEmpty && tn <= tf) ? tn : INFINITY;                                   \
         if (COUNT && (C) != kChildEmpty) nbox++;                                                \
     }
-                    if (QN) {
-                        /* quantised node: 4 x 16 B per lane.  child plane t = q * (s*inv) + (o*inv - off);
-                         * near/far planes chosen per axis by the sign of the direction */
-                        const uint4* qp = reinterpret_cast<const uint4*>(A.sv.qnodes + cur);
-                        const uint4 w0 = qp[0], w1 = qp[1], w2 = qp[2], w3 = qp[3];
-                        const uint32_t em = w0.w;
-                        const float nox = __uint_as_float(w0.x), noy = __uint_as_float(w0.y), noz = __uint_as_float(w0.z);
-                        const float sx = __uint_as_float((em & 0xffu) << 23) * ix;
-                        const float sy = __uint_as_float(((em >> 8) & 0xffu) << 23) * iy;
-                        const float sz = __uint_as_float(((em >> 16) & 0xffu) << 23) * iz;
-                        const float onx = fmaf(nox, ix, -ax), ofx = fmaf(nox, ix, -bx);
-                        const float ony = fmaf(noy, iy, -ay), ofy = fmaf(noy, iy, -by);
-                        const float onz = fmaf(noz, iz, -az), ofz = fmaf(noz, iz, -bz);
-                        const bool ngx = ix < 0.f, ngy = iy < 0.f, ngz = iz < 0.f;
-                        const uint32_t nwx = ngx ? w1.w : w1.x, fwx = ngx ? w1.x : w1.w;      /* qlo x,y,z = w1.xyz; qhi x,y,z = w1.w, w2.x, w2.y */
-                        const uint32_t nwy = ngy ? w2.x : w1.y, fwy = ngy ? w1.y : w2.x;
-                        const uint32_t nwz = ngz ? w2.y : w1.z, fwz = ngz ? w1.z : w2.y;
-                        c0 = w3.x; c1 = w3.y; c2 = w3.z; c3 = w3.w;
-#define QB(W, K) ((float)(((W) >> (8 * (K))) & 0xffu))
-#define SLAB_Q(K, TN, C)                                                                         \
-    {                                                                                            \
-        const float tnx = fmaf(QB(nwx, K), sx, onx), tfx = fmaf(QB(fwx, K), sx, ofx);            \
-        const float tny = fmaf(QB(nwy, K), sy, ony), tfy = fmaf(QB(fwy, K), sy, ofy);            \
-        const float tnz = fmaf(QB(nwz, K), sz, onz), tfz = fmaf(QB(fwz, K), sz, ofz);            \
-        const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, -1.0001e-4f));                        \
-        const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tbest));                              \
-        TN = ((C) != kChildEmpty && tn <= tf) ? tn : INFINITY;                                   \
-        if (COUNT && (C) != kChildEmpty) nbox++;                                                 \
-    }
-                        SLAB_Q(0, tn0, c0)
-                        SLAB_Q(1, tn1, c1)
-                        SLAB_Q(2, tn2, c2)
-                        SLAB_Q(3, tn3, c3)
-#undef SLAB_Q
-#undef QB
-                    } else {
+                    {
                         const float4* np = reinterpret_cast<const float4*>(A.sv.nodes + cur);
                         const float4 lox = np[0], loy = np[1], loz = np[2], hix = np[3], hiy = np[4], hiz = np[5];
                         const uint4 ch = reinterpret_cast<const uint4*>(np)[6];
@@ -381,93 +340,418 @@ __global__ CRT_TRACE_BOUNDS void k_trace(TraceArgs A, LightsParam LP) {
         atomicAdd(&A.counters[0], nbox);
         atomicAdd(&A.counters[1], ntri);
         atomicAdd(&A.counters[2], nsph);
+        atomicAdd(&A.counters[3], nvis);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * k_trace8: traversal of the compressed 8-wide tree (QNode8, layout.h) -- CRT_BVH_WIDE.
+ *
+ * The 4-wide kernel above is bound by VALU issue (profiles/r01c: SQ_INSTS_VALU = 100 % of the
+ * SIMDs' issue slots, ~250 VALU per node visit, 54 visits per ray on the 1M soup).  This kernel
+ * spends the instructions differently:
+ *   - a plane distance is one v_fma_mix_f32 on an fp16 plane code (no unpack, no convert);
+ *   - near/far plane rows are loaded by address (direction sign picks the row), no per-child selects;
+ *   - no distance sort and no per-child stack pushes: a node visit produces an 8-bit hit mask; the
+ *     internal hits stay together as ONE 64-bit stack entry (child base | imask | hits permuted
+ *     into front-to-back priority by the ray's octant, via a 2 KB LDS table), leaf hits are
+ *     tested before descending;
+ *   - 8 children per visit roughly halve the number of visits (dependent round trips) per ray.
+ * Scheduling (wave vote between node steps and primitive steps, chunked XCD-affine ray fetch,
+ * per-lane stack rows in LDS) is the same as in k_trace.
+ * ------------------------------------------------------------------------------------------ */
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+/* Slab test of child 2j (HI = false) or 2j+1 (HI = true) of a QNode8: the six plane codes are the
+ * lower / upper fp16 halves of six words.  A plane distance is ONE v_fma_mix_f32 (fp16 code x fp32
+ * scale + fp32 offset); the compiler's own choice for fmaf((float)h, s, b) is v_cvt_f32_f16 +
+ * v_pk_fma_f32, and it inserts a canonicalising v_max_f32 x,x after every asm result that feeds
+ * fmaxf/fminf -- so the whole ten-instruction sequence is written out here.
+ *   tn = max(tnx, tny, tnz, -1.0001e-4)      tf = min(tfx, tfy, tfz, tbest) */
+template <bool HI>
+CRT_DEV bool slab8(uint32_t wnx, uint32_t wfx, uint32_t wny, uint32_t wfy, uint32_t wnz, uint32_t wfz, float sx, float sy,
+                   float sz, float bnx, float bfx, float bny, float bfy, float bnz, float bfz, float tbest) {
+    float tn, tf, t1, t2;
+    if (HI)
+        asm("v_fma_mix_f32 %2, %4, %10, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %3, %6, %11, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %0, %8, %12, %17 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_max_f32 %0, 0xb8d1bc76, %0\n\t"
+            "v_max3_f32 %0, %2, %3, %0\n\t"
+            "v_fma_mix_f32 %2, %5, %10, %14 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %3, %7, %11, %16 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %1, %9, %12, %18 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_min_f32 %1, %1, %19\n\t"
+            "v_min3_f32 %1, %2, %3, %1"
+            : "=&v"(tn), "=&v"(tf), "=&v"(t1), "=&v"(t2)
+            : "v"(wnx), "v"(wfx), "v"(wny), "v"(wfy), "v"(wnz), "v"(wfz), "v"(sx), "v"(sy), "v"(sz), "v"(bnx), "v"(bfx),
+              "v"(bny), "v"(bfy), "v"(bnz), "v"(bfz), "v"(tbest));
+    else
+        asm("v_fma_mix_f32 %2, %4, %10, %13 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %3, %6, %11, %15 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %0, %8, %12, %17 op_sel_hi:[1,0,0]\n\t"
+            "v_max_f32 %0, 0xb8d1bc76, %0\n\t"
+            "v_max3_f32 %0, %2, %3, %0\n\t"
+            "v_fma_mix_f32 %2, %5, %10, %14 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %3, %7, %11, %16 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %1, %9, %12, %18 op_sel_hi:[1,0,0]\n\t"
+            "v_min_f32 %1, %1, %19\n\t"
+            "v_min3_f32 %1, %2, %3, %1"
+            : "=&v"(tn), "=&v"(tf), "=&v"(t1), "=&v"(t2)
+            : "v"(wnx), "v"(wfx), "v"(wny), "v"(wfy), "v"(wnz), "v"(wfz), "v"(sx), "v"(sy), "v"(sz), "v"(bnx), "v"(bfx),
+              "v"(bny), "v"(bfy), "v"(bnz), "v"(bfz), "v"(tbest));
+    return tn <= tf;
+}
+
+#if CRT_TRACE8_MIN_WAVES > 0
+#define CRT_TRACE8_BOUNDS __launch_bounds__(kTraceBlock, CRT_TRACE8_MIN_WAVES)
+#else
+#define CRT_TRACE8_BOUNDS __launch_bounds__(kTraceBlock)
+#endif
+template <int MODE, bool COUNT>
+__global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
+    __shared__ uint2 s_stack[kStackDepth8][kTraceBlock];
+    __shared__ uint8_t s_perm[8][256];     /* s_perm[R][m]: bit k of m moved to bit k ^ R */
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    for (int i = tid; i < 2048; i += kTraceBlock) {
+        const int R_ = i >> 8, m = i & 255;
+        int y = 0;
+        for (int k = 0; k < 8; k++) if ((m >> k) & 1) y |= 1 << (k ^ R_);
+        s_perm[R_][m] = (uint8_t)y;
+    }
+    __syncthreads();
+    const uint32_t total = *A.count;
+    const uint32_t gthread = blockIdx.x * kTraceBlock + tid;
+    uint2* ovf = reinterpret_cast<uint2*>(A.ovf) + (size_t)gthread * (size_t)(A.ovf_depth > 0 ? A.ovf_depth : 0);
+    const char* qbase = reinterpret_cast<const char*>(A.sv.qnodes);
+
+    bool active = false;
+    bool exhausted = false;
+    uint32_t cnext = 0, cend = 0;
+    const uint32_t xcd = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
+    const uint32_t per_region = (((total + 7u) >> 3) + 63u) & ~63u;
+    uint32_t region_k = 0;
+    vec3 o, d;
+    float ix = 0, iy = 0, iz = 0, anx = 0, afx = 0, any_ = 0, afy = 0, anz = 0, afz = 0;
+    uint32_t R = 0, rowx = kQ8PlaneX, rowy = kQ8PlaneY, rowz = kQ8PlaneZ;
+    float tbest = 0;
+    int best = -1;
+    uint32_t ray = 0;
+    uint32_t gbase = 0, gmask = 0;                 /* internal-child group: base node | imask << 8 | permuted hits */
+    uint32_t pbase = 0, meta0 = 0, meta1 = 0, lmask = 0;    /* leaf children hit at the last node, by slot */
+    uint32_t lp = 0, lend = 0;
+    int sp = 0;
+    int found = 0;
+    int lightj = 0;
+    unsigned long long nbox = 0, ntri = 0, nsph = 0, nvis = 0;
+
+    for (;;) {
+        if (!exhausted) {
+            const unsigned long long idle = __ballot(!active);
+            const int nidle = __popcll(idle);
+            if (nidle >= kRefillMinIdle) {
+                if (cnext >= cend) {
+                    bool got = false;
+                    while (region_k < 8 && !got) {
+                        const uint32_t r = (xcd + region_k) & 7u;
+                        const uint32_t rbeg = r * per_region;
+                        const uint32_t rend = rbeg + per_region < total ? rbeg + per_region : total;
+                        uint32_t base = 0xffffffffu;
+                        if (rbeg < rend) {
+                            if (lane == 0) base = atomicAdd(A.next + r * kFetchStride, (uint32_t)kFetchChunk);
+                            base = __builtin_amdgcn_readfirstlane(base);
+                        }
+                        if (rbeg < rend && base < rend - rbeg) {
+                            cnext = rbeg + base;
+                            cend = cnext + (uint32_t)kFetchChunk < rend ? cnext + (uint32_t)kFetchChunk : rend;
+                            got = true;
+                        } else region_k++;
+                    }
+                    if (!got) exhausted = true;
+                }
+                if (!exhausted) {
+                    const uint32_t idx = cnext + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                    const uint32_t take = (uint32_t)nidle < cend - cnext ? (uint32_t)nidle : cend - cnext;
+                    const bool mine = !active && idx < cend;
+                    cnext += take;
+                    if (mine) {
+                        const float4 ro = A.rayO[idx], rd = A.rayD[idx];
+                        if (MODE == TRACE_NEAREST && __float_as_uint(rd.w) == 0xffffffffu) {
+                            A.hitSlot[idx] = -3;
+                            A.hitT[idx] = 0.f;
+                        } else {
+                            ray = idx;
+                            o = vec3(ro.x, ro.y, ro.z); d = vec3(rd.x, rd.y, rd.z);
+                            if (MODE == TRACE_SHADOW) { ray = __float_as_uint(ro.w); lightj = (int)__float_as_uint(rd.w); }
+                            float rx = 1.0f / d.x, ry = 1.0f / d.y, rz = 1.0f / d.z;
+                            if (!(fabsf(d.x) > 1e-20f)) rx = copysignf(1e20f, d.x);
+                            if (!(fabsf(d.y) > 1e-20f)) ry = copysignf(1e20f, d.y);
+                            if (!(fabsf(d.z) > 1e-20f)) rz = copysignf(1e20f, d.z);
+                            ix = rx; iy = ry; iz = rz;
+                            /* boxes are conservative already; the pad covers the rounding of the plane arithmetic */
+                            const float px = 1e-3f + 1e-6f * (fabsf(o.x) + A.scene_abs);
+                            const float py = 1e-3f + 1e-6f * (fabsf(o.y) + A.scene_abs);
+                            const float pz = 1e-3f + 1e-6f * (fabsf(o.z) + A.scene_abs);
+                            const bool ngx = ix < 0.f, ngy = iy < 0.f, ngz = iz < 0.f;
+                            /* near plane: lo row shifted by -pad for a positive direction, hi row by +pad for a negative one */
+                            anx = (ngx ? o.x - px : o.x + px) * ix; afx = (ngx ? o.x + px : o.x - px) * ix;
+                            any_ = (ngy ? o.y - py : o.y + py) * iy; afy = (ngy ? o.y + py : o.y - py) * iy;
+                            anz = (ngz ? o.z - pz : o.z + pz) * iz; afz = (ngz ? o.z + pz : o.z - pz) * iz;
+                            rowx = kQ8PlaneX + (ngx ? 16u : 0u);
+                            rowy = kQ8PlaneY + (ngy ? 16u : 0u);
+                            rowz = kQ8PlaneZ + (ngz ? 16u : 0u);
+                            R = (ngx ? 0u : 4u) | (ngy ? 0u : 2u) | (ngz ? 0u : 1u);
+                            tbest = 1000000000.0f; best = -1; sp = 0; found = 0; lp = lend = 0; lmask = 0;
+                            gbase = 0; gmask = (1u << 8) | (1u << R);      /* a group whose only child is the root */
+                            active = true;
+                        }
+                    }
+                }
+            }
+        }
+        if (__ballot(active) == 0ull) { if (exhausted) break; else continue; }
+
+        do {
+            const bool want_prim = active && (lp < lend || lmask != 0u);
+            const bool want_node = active && !want_prim;
+            const int n_node = __popcll(__ballot(want_node));
+            const int n_prim = __popcll(__ballot(want_prim));
+            bool finish = false;
+            if (n_node * CRT_VOTE8_PRIM_WEIGHT >= n_prim * CRT_VOTE8_NODE_WEIGHT) {
+                if (want_node) {
+                    if ((gmask & 0xffu) == 0u) {
+                        if (sp == 0) finish = true;
+                        else {
+                            sp--;
+                            uint2 e;
+                            if (sp < kStackDepth8) e = s_stack[sp][tid];
+                            else if (sp - kStackDepth8 < A.ovf_depth) e = ovf[sp - kStackDepth8];
+                            else { e = make_uint2(0u, 0u); finish = true; }
+                            gbase = e.x; gmask = e.y;
+                        }
+                    }
+                    if (!finish) {
+                        const uint32_t pbit = 31u - (uint32_t)__clz((int)(gmask & 0xffu));
+                        const uint32_t slot = pbit ^ R;
+                        gmask ^= 1u << pbit;
+                        const uint32_t node = gbase + (uint32_t)__popc((gmask >> 8) & ((1u << slot) - 1u));
+                        if (gmask & 0xffu) {
+                            if (sp < kStackDepth8) s_stack[sp][tid] = make_uint2(gbase, gmask);
+                            else if (sp - kStackDepth8 < A.ovf_depth) ovf[sp - kStackDepth8] = make_uint2(gbase, gmask);
+                            else atomicOr(A.status, 1u);
+                            sp++;
+                        }
+                        /* 32-bit byte offsets from the uniform base (nodes < 2^24): scalar base + vector offset addressing */
+                        const uint32_t noff = node * (uint32_t)sizeof(QNode8);
+                        const uint4 h0 = *reinterpret_cast<const uint4*>(qbase + noff);
+                        const uint4 h1 = *reinterpret_cast<const uint4*>(qbase + (noff + 16u));
+                        const uint4 NX = *reinterpret_cast<const uint4*>(qbase + (noff + rowx));
+                        const uint4 FX = *reinterpret_cast<const uint4*>(qbase + (noff + (rowx ^ 16u)));
+                        const uint4 NY = *reinterpret_cast<const uint4*>(qbase + (noff + rowy));
+                        const uint4 FY = *reinterpret_cast<const uint4*>(qbase + (noff + (rowy ^ 16u)));
+                        const uint4 NZ = *reinterpret_cast<const uint4*>(qbase + (noff + rowz));
+                        const uint4 FZ = *reinterpret_cast<const uint4*>(qbase + (noff + (rowz ^ 16u)));
+                        const uint32_t em = h0.w;
+                        const float nox = __uint_as_float(h0.x), noy = __uint_as_float(h0.y), noz = __uint_as_float(h0.z);
+                        const float sx = __uint_as_float((em << 23) & 0x7f800000u) * ix;
+                        const float sy = __uint_as_float((em << 15) & 0x7f800000u) * iy;
+                        const float sz = __uint_as_float((em << 7) & 0x7f800000u) * iz;
+                        const float bnx = fmaf(nox, ix, -anx), bfx = fmaf(nox, ix, -afx);
+                        const float bny = fmaf(noy, iy, -any_), bfy = fmaf(noy, iy, -afy);
+                        const float bnz = fmaf(noz, iz, -anz), bfz = fmaf(noz, iz, -afz);
+                        uint32_t raw = 0;
+#define SLAB8(K, HI, C)                                                                                 \
+    raw |= slab8<HI>(NX.C, FX.C, NY.C, FY.C, NZ.C, FZ.C, sx, sy, sz, bnx, bfx, bny, bfy, bnz, bfz, tbest) ? (1u << (K)) : 0u;
+                        SLAB8(0, false, x) SLAB8(1, true, x) SLAB8(2, false, y) SLAB8(3, true, y)
+                        SLAB8(4, false, z) SLAB8(5, true, z) SLAB8(6, false, w) SLAB8(7, true, w)
+#undef SLAB8
+                        const uint32_t vmask = h1.x >> 24, imask = em >> 24;
+                        raw &= vmask;                       /* an empty slot can pass the padded test of a degenerate node */
+                        if (COUNT) { nbox += (unsigned long long)__popc(vmask); nvis++; }
+                        gbase = h1.x & 0xffffffu;
+                        gmask = (imask << 8) | (uint32_t)s_perm[R][raw & imask];
+                        lmask = raw & ~imask;
+                        pbase = h1.y; meta0 = h1.z; meta1 = h1.w;
+                        if (raw == 0u && sp == 0) finish = true;
+                    }
+                }
+            } else {
+                if (want_prim) {
+                    if (lp == lend) {
+                        const uint32_t k = (uint32_t)__ffs((int)lmask) - 1u;
+                        lmask &= lmask - 1u;
+                        const uint32_t m = ((k & 4u) ? meta1 : meta0) >> ((k & 3u) * 8u);
+                        lp = pbase + (m & 31u);
+                        lend = lp + ((m >> 5) & 3u) + 1u;
+                    }
+                    const uint32_t p = lp++;
+                    const GeomRec g = load_geom(A.sv.geom, p);
+                    float t = 0.f, tsm;
+                    bool hit;
+                    if (is_sphere(g)) { if (COUNT) nsph++; hit = sphere_test(g, o, d, t, tsm); }
+                    else { if (COUNT) ntri++; hit = tri_test(g, o, d, tbest, t); }
+                    if (hit) {
+                        if (MODE == TRACE_NEAREST) {
+                            if (t < tbest || (t == tbest && best >= 0 && A.sv.rank[p] < A.sv.rank[best])) { tbest = t; best = (int)p; }
+                        } else {
+                            if (LP.l[lightj].point) {
+                                if (t < tbest) { tbest = t; best = (int)p; }
+                            } else {
+                                if (!(t > 0.000000001f)) { found = 0; finish = true; }
+                                else { found = 1; if (tbest > 0.000000001f) tbest = 0.000000001f; }
+                            }
+                        }
+                    }
+                    if (lp == lend && lmask == 0u && (gmask & 0xffu) == 0u && sp == 0) finish = true;
+                }
+            }
+            if (finish) {
+                if (MODE == TRACE_NEAREST) {
+                    A.hitSlot[ray] = best;
+                    A.hitT[ray] = tbest;
+                } else {
+                    bool shadowed;
+                    if (LP.l[lightj].point) {
+                        shadowed = false;
+                        if (best >= 0) {
+                            const vec3 lpos(LP.l[lightj].position);
+                            const vec3 ipoint = o + tbest * d;
+                            const float ex = o.x - lpos.x, ey = o.y - lpos.y, ez = o.z - lpos.z;
+                            const float dtoLight = sqrtf(ex * ex + ey * ey + ez * ez);
+                            const float fx = ipoint.x - o.x, fy = ipoint.y - o.y, fz = ipoint.z - o.z;
+                            const float dtoLightIntersection = sqrtf(fx * fx + fy * fy + fz * fz);
+                            shadowed = dtoLight > dtoLightIntersection;
+                        }
+                    } else shadowed = (found != 0);
+                    if (shadowed) A.shflag[ray] = 1;
+                }
+                active = false; lp = lend = 0; lmask = 0;
+            }
+        } while (exhausted ? (__ballot(active) != 0ull) : (__popcll(__ballot(active)) > 64 - kRefillMinIdle));
+    }
+    if (COUNT) {
+        atomicAdd(&A.counters[0], nbox);
+        atomicAdd(&A.counters[1], ntri);
+        atomicAdd(&A.counters[2], nsph);
+        atomicAdd(&A.counters[3], nvis);
     }
 }
 
 int trace_grid_blocks(int device) {
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device) != hipSuccess) return 1024;
-    /* persistent grid = what is resident at once: limited by the 32 KB LDS stack per block (5 blocks
-     * per CU) and by the kernel's VGPR allocation; ask the runtime for the tighter of the two */
+    /* persistent grid = what is resident at once: limited by the LDS stack per block and by the
+     * kernel's VGPR allocation; ask the runtime for the tighter of the two */
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<TRACE_NEAREST, false, true>, kTraceBlock, 0) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace8<TRACE_NEAREST, false>, kTraceBlock, 0) != hipSuccess || per_cu < 1)
         per_cu = 4;
     if (per_cu > 8) per_cu = 8;
     return p.multiProcessorCount * per_cu;
 }
 
-template <int MODE>
-static void launch_trace_mode(const TraceArgs& a, const LightsParam& lights, bool counting, bool quantised, dim3 g, dim3 b, hipStream_t s) {
-    if (quantised) {
-        if (counting) hipLaunchKernelGGL((k_trace<MODE, true, true>), g, b, 0, s, a, lights);
-        else hipLaunchKernelGGL((k_trace<MODE, false, true>), g, b, 0, s, a, lights);
-    } else {
-        if (counting) hipLaunchKernelGGL((k_trace<MODE, true, false>), g, b, 0, s, a, lights);
-        else hipLaunchKernelGGL((k_trace<MODE, false, false>), g, b, 0, s, a, lights);
-    }
-}
-void launch_trace(const TraceArgs& a, const LightsParam& lights, int mode, bool counting, bool quantised, int blocks, hipStream_t s) {
+void launch_trace(const TraceArgs& a, const LightsParam& lights, int mode, bool counting, bool wide, int blocks, hipStream_t s) {
     dim3 g(blocks), b(kTraceBlock);
-    if (mode == TRACE_NEAREST) launch_trace_mode<TRACE_NEAREST>(a, lights, counting, quantised, g, b, s);
-    else launch_trace_mode<TRACE_SHADOW>(a, lights, counting, quantised, g, b, s);
+    if (wide) {
+        if (mode == TRACE_NEAREST) {
+            if (counting) hipLaunchKernelGGL((k_trace8<TRACE_NEAREST, true>), g, b, 0, s, a, lights);
+            else hipLaunchKernelGGL((k_trace8<TRACE_NEAREST, false>), g, b, 0, s, a, lights);
+        } else {
+            if (counting) hipLaunchKernelGGL((k_trace8<TRACE_SHADOW, true>), g, b, 0, s, a, lights);
+            else hipLaunchKernelGGL((k_trace8<TRACE_SHADOW, false>), g, b, 0, s, a, lights);
+        }
+    } else {
+        if (mode == TRACE_NEAREST) {
+            if (counting) hipLaunchKernelGGL((k_trace<TRACE_NEAREST, true>), g, b, 0, s, a, lights);
+            else hipLaunchKernelGGL((k_trace<TRACE_NEAREST, false>), g, b, 0, s, a, lights);
+        } else {
+            if (counting) hipLaunchKernelGGL((k_trace<TRACE_SHADOW, true>), g, b, 0, s, a, lights);
+            else hipLaunchKernelGGL((k_trace<TRACE_SHADOW, false>), g, b, 0, s, a, lights);
+        }
+    }
 }
 
 /* ------------------------------------------------------------------------------------------
- * k_quantize: Node4 (exact child bounds) -> QNode (8-bit bounds relative to the node's own box,
- * rounded outward; checked in double so that every quantised box contains the exact one).
- * Runs after every build and refit of the wide tree.
+ * k_quantize8: Node8 (exact child bounds) -> QNode8.  Plane codes are integers 0..2047 on a
+ * power-of-two grid anchored at the node's own box, rounded outward and checked in double so that
+ * every quantised box contains the exact one.  Runs after every build and refit of the wide tree.
  * ------------------------------------------------------------------------------------------ */
-__global__ __launch_bounds__(256) void k_quantize(const Node4* nodes, uint32_t nnodes, QNode* qnodes) {
+__global__ __launch_bounds__(256) void k_quantize8(const Node8* nodes, uint32_t nnodes, QNode8* qnodes, uint32_t* status) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nnodes) return;
-    const Node4& nd = nodes[i];
-    float lo[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
-    float hi[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
-    for (int k = 0; k < 4; k++) {
-        if (nd.child[k] == kChildEmpty) continue;
-        lo[0] = fminf(lo[0], nd.lox[k]); lo[1] = fminf(lo[1], nd.loy[k]); lo[2] = fminf(lo[2], nd.loz[k]);
-        hi[0] = fmaxf(hi[0], nd.hix[k]); hi[1] = fmaxf(hi[1], nd.hiy[k]); hi[2] = fmaxf(hi[2], nd.hiz[k]);
+    const Node8& nd = nodes[i];
+    QNode8 q;
+    uint32_t imask = 0, vmask = 0, cbase = 0xffffffffu, pb = 0xffffffffu;
+    for (int k = 0; k < 8; k++) {
+        const uint32_t l = nd.child[k];
+        if (l == kChildEmpty) continue;
+        vmask |= 1u << k;
+        if (l & kLeafFlag) { const uint32_t st = l & kLeafStartMask; if (st < pb) pb = st; }
+        else { imask |= 1u << k; if (l < cbase) cbase = l; }
     }
-    QNode q;
-    uint8_t ex[3];
+    if (cbase == 0xffffffffu) cbase = 0;
+    if (pb == 0xffffffffu) pb = 0;
+    bool bad = false;
+    uint32_t nint = 0;
+    for (int k = 0; k < 8; k++) {
+        const uint32_t l = nd.child[k];
+        q.meta[k] = 0;
+        if (l == kChildEmpty) continue;
+        if (l & kLeafFlag) {
+            const uint32_t off = (l & kLeafStartMask) - pb, cnt = ((l >> kLeafCountShift) & 63u) + 1u;
+            if (off > 31u || cnt > (uint32_t)kWide8LeafMax) bad = true;
+            q.meta[k] = (uint8_t)(0x80u | ((cnt - 1u) << 5) | (off & 31u));
+        } else {
+            if (l != cbase + nint) bad = true;          /* internal children must be consecutive in slot order */
+            nint++;
+        }
+    }
+    if (bad || cbase >= (1u << 24)) atomicOr(status, 2u);
+    float org[3];
+    uint32_t ex[3];
     for (int a = 0; a < 3; a++) {
-        const float clo[4] = {a == 0 ? nd.lox[0] : a == 1 ? nd.loy[0] : nd.loz[0], a == 0 ? nd.lox[1] : a == 1 ? nd.loy[1] : nd.loz[1],
-                              a == 0 ? nd.lox[2] : a == 1 ? nd.loy[2] : nd.loz[2], a == 0 ? nd.lox[3] : a == 1 ? nd.loy[3] : nd.loz[3]};
-        const float chi[4] = {a == 0 ? nd.hix[0] : a == 1 ? nd.hiy[0] : nd.hiz[0], a == 0 ? nd.hix[1] : a == 1 ? nd.hiy[1] : nd.hiz[1],
-                              a == 0 ? nd.hix[2] : a == 1 ? nd.hiy[2] : nd.hiz[2], a == 0 ? nd.hix[3] : a == 1 ? nd.hiy[3] : nd.hiz[3]};
-        const float o = lo[a] <= hi[a] ? lo[a] : 0.f;
-        const float ext = lo[a] <= hi[a] ? hi[a] - lo[a] : 0.f;
-        /* smallest power of two s with 254*s >= extent (one code of headroom for outward rounding) */
+        const float* clo = a == 0 ? nd.lox : a == 1 ? nd.loy : nd.loz;
+        const float* chi = a == 0 ? nd.hix : a == 1 ? nd.hiy : nd.hiz;
+        uint16_t* qlo = a == 0 ? q.lo_x : a == 1 ? q.lo_y : q.lo_z;
+        uint16_t* qhi = a == 0 ? q.hi_x : a == 1 ? q.hi_y : q.hi_z;
+        float lo = 3.402823466e+38f, hi = -3.402823466e+38f;
+        for (int k = 0; k < 8; k++) if (vmask & (1u << k)) { lo = fminf(lo, clo[k]); hi = fmaxf(hi, chi[k]); }
+        const float o = lo <= hi ? lo : 0.f;
+        const float ext = lo <= hi ? hi - lo : 0.f;
+        /* smallest power of two s with (kQ8Grid - 1) * s >= extent (one code of headroom for outward rounding) */
         int e = 0;
-        (void)frexpf(ext / 254.0f, &e);
+        (void)frexpf(ext / (float)(kQ8Grid - 1), &e);
         float sc = ldexpf(1.0f, e);
         if (!(ext > 0.f)) sc = ldexpf(1.0f, -60);
         for (int attempt = 0; attempt < 4; attempt++) {
             bool fits = true;
-            for (int k = 0; k < 4; k++) {
-                uint32_t ql = 0, qh = 0;
-                if (nd.child[k] != kChildEmpty) {
+            for (int k = 0; k < 8; k++) {
+                uint32_t ql = (uint32_t)kQ8Grid, qh = 0;       /* empty slot: inverted */
+                if (vmask & (1u << k)) {
                     float fl = floorf((clo[k] - o) / sc), fh = ceilf((chi[k] - o) / sc);
-                    fl = fminf(fmaxf(fl, 0.f), 255.f); fh = fminf(fmaxf(fh, 0.f), 255.f);
+                    fl = fminf(fmaxf(fl, 0.f), (float)kQ8Grid); fh = fminf(fmaxf(fh, 0.f), (float)kQ8Grid);
                     ql = (uint32_t)fl; qh = (uint32_t)fh;
                     while (ql > 0 && (double)o + (double)ql * (double)sc > (double)clo[k]) ql--;
-                    while (qh < 255 && (double)o + (double)qh * (double)sc < (double)chi[k]) qh++;
+                    while (qh < (uint32_t)kQ8Grid && (double)o + (double)qh * (double)sc < (double)chi[k]) qh++;
                     if ((double)o + (double)ql * (double)sc > (double)clo[k] || (double)o + (double)qh * (double)sc < (double)chi[k]) fits = false;
                 }
-                q.qlo[a][k] = (uint8_t)ql; q.qhi[a][k] = (uint8_t)qh;
+                const _Float16 hl = (_Float16)(float)ql, hh = (_Float16)(float)qh;    /* integers <= 2047 are exact in fp16 */
+                qlo[k] = __builtin_bit_cast(uint16_t, hl); qhi[k] = __builtin_bit_cast(uint16_t, hh);
             }
             if (fits) break;
             sc *= 2.0f;
         }
-        ex[a] = (uint8_t)((__float_as_uint(sc) >> 23) & 0xffu);
-        if (a == 0) q.ox = o; else if (a == 1) q.oy = o; else q.oz = o;
+        ex[a] = (__float_as_uint(sc) >> 23) & 0xffu;
+        org[a] = o;
     }
-    q.ex = ex[0]; q.ey = ex[1]; q.ez = ex[2]; q.pad0 = 0; q.pad1[0] = q.pad1[1] = 0;
-    for (int k = 0; k < 4; k++) q.child[k] = nd.child[k];
+    q.ox = org[0]; q.oy = org[1]; q.oz = org[2];
+    q.exps_imask = ex[0] | (ex[1] << 8) | (ex[2] << 16) | (imask << 24);
+    q.base_vmask = cbase | (vmask << 24);
+    q.prim_base = pb;
     qnodes[i] = q;
 }
-void launch_quantize(const Node4* nodes, uint32_t nnodes, QNode* qnodes, hipStream_t s) {
-    if (nnodes) hipLaunchKernelGGL(k_quantize, dim3((nnodes + 255u) / 256u), dim3(256), 0, s, nodes, nnodes, qnodes);
+void launch_quantize(const Node8* nodes, uint32_t nnodes, QNode8* qnodes, uint32_t* status, hipStream_t s) {
+    if (nnodes) hipLaunchKernelGGL(k_quantize8, dim3((nnodes + 255u) / 256u), dim3(256), 0, s, nodes, nnodes, qnodes, status);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -878,11 +1162,12 @@ void launch_pack_prims(const crt_prim* d_prims, const uint32_t* d_matid, const u
  * arrive at a parent (agent-scope arrival counter) carries on.  grow_only keeps the reference's
  * "boxes never shrink" rule; min/max are exact, so the result is order independent.
  * ------------------------------------------------------------------------------------------ */
-__global__ __launch_bounds__(256) void k_refit_leaves(Node4* nodes, uint32_t nnodes, const Geom* geom, int grow_only) {
+template <class N>
+__global__ __launch_bounds__(256) void k_refit_leaves(N* nodes, uint32_t nnodes, const Geom* geom, int grow_only) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= nnodes * 4u) return;
-    Node4& nd = nodes[id >> 2];
-    const int k = (int)(id & 3u);
+    if (id >= nnodes * (uint32_t)N::W) return;
+    N& nd = nodes[id / (uint32_t)N::W];
+    const int k = (int)(id % (uint32_t)N::W);
     const uint32_t link = nd.child[k];
     if (link == kChildEmpty || !(link & kLeafFlag)) return;
     const uint32_t start = link & kLeafStartMask, cnt = ((link >> kLeafCountShift) & 63u) + 1u;
@@ -907,16 +1192,17 @@ __global__ __launch_bounds__(256) void k_refit_leaves(Node4* nodes, uint32_t nno
     nd.hix[k] = hi[0]; nd.hiy[k] = hi[1]; nd.hiz[k] = hi[2];
 }
 
-__global__ __launch_bounds__(256) void k_refit_up(Node4* nodes, uint32_t nnodes, uint32_t* arrive, float* root_box, int grow_only) {
+template <class N>
+__global__ __launch_bounds__(256) void k_refit_up(N* nodes, uint32_t nnodes, uint32_t* arrive, float* root_box, int grow_only) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= nnodes) return;
     if (nodes[id].n_internal != 0) return;
     uint32_t cur = id;
     for (int guard = 0; guard < 4096; guard++) {
-        const Node4& nd = nodes[cur];
+        const N& nd = nodes[cur];
         float lo[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
         float hi[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < N::W; k++) {
             lo[0] = fminf(lo[0], nd.lox[k]); lo[1] = fminf(lo[1], nd.loy[k]); lo[2] = fminf(lo[2], nd.loz[k]);
             hi[0] = fmaxf(hi[0], nd.hix[k]); hi[1] = fmaxf(hi[1], nd.hiy[k]); hi[2] = fmaxf(hi[2], nd.hiz[k]);
         }
@@ -930,7 +1216,7 @@ __global__ __launch_bounds__(256) void k_refit_up(Node4* nodes, uint32_t nnodes,
             root_box[0] = lo[0]; root_box[1] = hi[0]; root_box[2] = lo[1]; root_box[3] = hi[1]; root_box[4] = lo[2]; root_box[5] = hi[2];
             return;
         }
-        Node4& pn = nodes[parent];
+        N& pn = nodes[parent];
         const int k = (int)nd.parent_slot;
         if (grow_only) {
             lo[0] = fminf(lo[0], pn.lox[k]); lo[1] = fminf(lo[1], pn.loy[k]); lo[2] = fminf(lo[2], pn.loz[k]);
@@ -951,12 +1237,18 @@ __global__ __launch_bounds__(256) void k_refit_up(Node4* nodes, uint32_t nnodes,
     }
 }
 
-void launch_refit(Node4* nodes, uint32_t nnodes, const Geom* geom, uint32_t* arrive, float* root_box, int grow_only,
-                  hipStream_t s) {
+template <class N>
+static void launch_refit_t(N* nodes, uint32_t nnodes, const Geom* geom, uint32_t* arrive, float* root_box, int grow_only, hipStream_t s) {
     if (nnodes == 0) return;
-    hipMemsetAsync(arrive, 0, sizeof(uint32_t) * nnodes, s);
-    hipLaunchKernelGGL(k_refit_leaves, dim3((nnodes * 4u + 255u) / 256u), dim3(256), 0, s, nodes, nnodes, geom, grow_only);
-    hipLaunchKernelGGL(k_refit_up, dim3((nnodes + 255u) / 256u), dim3(256), 0, s, nodes, nnodes, arrive, root_box, grow_only);
+    (void)hipMemsetAsync(arrive, 0, sizeof(uint32_t) * nnodes, s);
+    hipLaunchKernelGGL((k_refit_leaves<N>), dim3((nnodes * (uint32_t)N::W + 255u) / 256u), dim3(256), 0, s, nodes, nnodes, geom, grow_only);
+    hipLaunchKernelGGL((k_refit_up<N>), dim3((nnodes + 255u) / 256u), dim3(256), 0, s, nodes, nnodes, arrive, root_box, grow_only);
+}
+void launch_refit(Node4* nodes, uint32_t nnodes, const Geom* geom, uint32_t* arrive, float* root_box, int grow_only, hipStream_t s) {
+    launch_refit_t(nodes, nnodes, geom, arrive, root_box, grow_only, s);
+}
+void launch_refit8(Node8* nodes, uint32_t nnodes, const Geom* geom, uint32_t* arrive, float* root_box, int grow_only, hipStream_t s) {
+    launch_refit_t(nodes, nnodes, geom, arrive, root_box, grow_only, s);
 }
 
 /* ------------------------------------------------------------------------------------------

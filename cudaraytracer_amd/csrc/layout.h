@@ -3,12 +3,12 @@
  * One contiguous device allocation, so that replicating the scene to another GPU is a single
  * broadcast.  Sections (all 256-byte aligned, offsets in BlobHeader):
  *
- *   nodes   nnodes x 128 B   4-wide BVH node: exact child bounds SoA + child links + parent link.
- *                            Master copy: refit and dumps work on it; the kernels traverse it only
- *                            for the reference topology.
- *   qnodes  nnodes x  64 B   the same tree quantised for traversal (wide mode): node origin + per-axis
- *                            power-of-two scale, 8-bit conservative child bounds, explicit child
- *                            links.  4 x 16-byte loads per lane per visit instead of 7.
+ *   nodes   exact child bounds SoA + child links + parent link; master copy for refit and dumps.
+ *                            CRT_BVH_REFERENCE: nnodes x 128 B Node4 (two slots used), traversed as is.
+ *                            CRT_BVH_WIDE:      nnodes x 256 B Node8.
+ *   qnodes  nnodes x 128 B   CRT_BVH_WIDE only: the 8-wide tree compressed for traversal (QNode8):
+ *                            node origin + per-axis power-of-two scale, fp16 conservative child
+ *                            planes, two base indices instead of links.
  *   geom    nprims x  48 B   hit-test record, indexed by SLOT (leaf order of the packed tree)
  *                              triangle: v1.xyz v2.xyz v3.xyz Ng.xyz   (Ng precomputed exactly as Ray.cu:145)
  *                              sphere:   c.xyz r | dot(c,c) r*r 0 0 | 0 SPHERE_TAG 0 0
@@ -28,7 +28,7 @@
 namespace crt {
 
 constexpr uint32_t kBlobMagic = 0x43525442u;   /* "CRTB" */
-constexpr uint32_t kBlobVersion = 3;
+constexpr uint32_t kBlobVersion = 4;
 constexpr uint32_t kSphereTag = 0x7fc5fe3eu;   /* quiet NaN with a payload no arithmetic produces */
 constexpr uint32_t kChildEmpty = 0xffffffffu;
 constexpr uint32_t kLeafFlag = 0x80000000u;
@@ -42,6 +42,7 @@ static inline uint32_t make_leaf(uint32_t start, uint32_t count) {
 }
 
 struct alignas(128) Node4 {
+    static constexpr int W = 4;
     float lox[4], loy[4], loz[4];
     float hix[4], hiy[4], hiz[4];
     uint32_t child[4];        /* internal: node index; leaf: make_leaf(); unused: kChildEmpty */
@@ -52,20 +53,41 @@ struct alignas(128) Node4 {
 };
 static_assert(sizeof(Node4) == 128, "Node4 must be 128 bytes");
 
-/* Quantised traversal node, 64 B = 4 x 16-byte loads per lane per visit (the exact node needs 7).
- * Child k's box is [o + qlo*s, o + qhi*s] per axis with s = 2^(e-127) taken from the exponent
- * byte; quantisation rounds outward, so the box contains the exact one.  Child links are the
- * same 32-bit links as Node4::child (explicit: deriving them from base indices cost ~35 VALU
- * instructions per visit in a kernel that is bound by VALU issue). */
-struct alignas(16) QNode {
-    float ox, oy, oz;
-    uint8_t ex, ey, ez, pad0;
-    uint8_t qlo[3][4];
-    uint8_t qhi[3][4];
-    uint32_t pad1[2];
-    uint32_t child[4];
+/* Exact 8-wide node of the wide tree (CRT_BVH_WIDE): master copy for refit, dumps and the
+ * quantiser.  Internal children of a node are consecutive nodes in slot order and its leaf
+ * primitives one contiguous slot range, which is what lets the traversal node below carry two
+ * base indices instead of eight links. */
+struct alignas(256) Node8 {
+    static constexpr int W = 8;
+    float lox[8], loy[8], loz[8];
+    float hix[8], hiy[8], hiz[8];
+    uint32_t child[8];        /* same link format as Node4::child */
+    uint32_t parent, parent_slot, n_internal, pad;
+    uint32_t pad2[4];
 };
-static_assert(sizeof(QNode) == 64, "QNode must be 64 bytes");
+static_assert(sizeof(Node8) == 256, "Node8 must be 256 bytes");
+
+/* Compressed 8-wide traversal node: one 128-byte line = 8 x 16-byte loads per lane per visit.
+ * Child k's box is [o + lo*s, o + hi*s] per axis with s = 2^(e-127); lo/hi are fp16 values that
+ * hold integers 0..2047 (exact in fp16), rounded outward, so the box contains the exact one and a
+ * plane distance is ONE v_fma_mix_f32 (fp16 x fp32 + fp32) -- no unpack/convert instructions.
+ * The six plane rows are separate 16-byte blocks so that a lane loads its ray's NEAR and FAR rows
+ * directly (row address picked by the direction sign, far = near ^ 16) instead of selecting per
+ * child.  Slots are assigned by octant (slot bit 4/2/1 = child on the +x/+y/+z side of the node
+ * centre): visiting hit children in descending (slot ^ R), R = the ray's octant code, is a
+ * front-to-back order without computing or sorting distances. */
+struct alignas(128) QNode8 {
+    float ox, oy, oz;
+    uint32_t exps_imask;      /* ex | ey << 8 | ez << 16 | imask << 24; imask bit k: child k is a node */
+    uint32_t base_vmask;      /* first internal child (node index, < 2^24) | vmask << 24; vmask bit k: child k exists */
+    uint32_t prim_base;       /* first slot of this node's leaf primitives */
+    uint8_t meta[8];          /* leaf child k: 0x80 | (count-1) << 5 | (first slot - prim_base); else 0 */
+    uint16_t lo_x[8], hi_x[8], lo_y[8], hi_y[8], lo_z[8], hi_z[8];
+};
+static_assert(sizeof(QNode8) == 128, "QNode8 must be 128 bytes");
+constexpr uint32_t kQ8PlaneX = 32, kQ8PlaneY = 64, kQ8PlaneZ = 96;   /* byte offsets of the lo rows; hi = lo + 16 */
+constexpr int kQ8Grid = 2047;           /* largest integer stored in a plane */
+constexpr int kWide8LeafMax = 4;        /* primitives per leaf of the wide tree (2 bits in meta) */
 
 struct alignas(16) Geom { float w[12]; };
 struct alignas(16) Shade { float n[9]; uint32_t mat; uint32_t pad[2]; };
@@ -86,8 +108,8 @@ static_assert(sizeof(BlobHeader) % 16 == 0, "header alignment");
 
 /* Device-side view: raw pointers into the blob. */
 struct SceneView {
-    const Node4* nodes;
-    const QNode* qnodes;
+    const Node4* nodes;       /* CRT_BVH_REFERENCE only */
+    const QNode8* qnodes;     /* CRT_BVH_WIDE only */
     const Geom* geom;
     const Shade* shade;
     const uint32_t* rank;

@@ -88,6 +88,7 @@ typedef struct crt_stats {
     int32_t nodes, prims, depth, leaves;
     double ms_build_host, ms_refit;
     uint64_t scene_bytes;    /* packed scene + BVH bytes resident in HBM */
+    uint64_t node_visits, node_visits_shadow;   /* counting only: BVH nodes visited (one visit tests all its children) */
 } crt_stats;
 
 typedef struct crt_ctx crt_ctx;
@@ -107,8 +108,8 @@ int crt_lights_set(crt_ctx*, const crt_light* lights, int n);
 
 /* ---- BVH: replaces newBuild+constructTree (main.cu:33-136, bvh.cu:12-273), refitTree
  *      (bvh.cu:288-400) and freeTree (bvh.cu:274-286) ---- */
-#define CRT_BVH_WIDE 0       /* binned-SAH tree collapsed to 4-wide nodes, <=4 primitives per leaf */
-#define CRT_BVH_REFERENCE 1  /* the reference's topology (mean-centroid split, <=64 per leaf) in the same node format */
+#define CRT_BVH_WIDE 0       /* binned-SAH tree collapsed to compressed 8-wide nodes, <=4 primitives per leaf */
+#define CRT_BVH_REFERENCE 1  /* the reference's topology (mean-centroid split, <=64 per leaf), exact boxes */
 int crt_bvh_build(crt_ctx*, int mode);
 #define CRT_REFIT_TIGHT 0
 #define CRT_REFIT_GROW 1     /* boxes only grow, as refitTree does */
@@ -118,9 +119,11 @@ int crt_bvh_free(crt_ctx*);
  * the lower rank, as the strict '<' at Ray.cu:199,216 does.  out[n] indexed by scene index. */
 int crt_bvh_reference_order(crt_ctx*, int32_t* rank_out, int n);
 /* Node boxes after build/refit, for parity checks of the refit kernel: 6 floats per stored child
- * box in node order (minX,maxX,minY,maxY,minZ,maxZ), plus the root box first. */
-int crt_bvh_dump(crt_ctx*, int32_t* nnodes, float* root_box6, float* child_boxes /* nnodes*4*6 */,
-                 uint32_t* child_links /* nnodes*4 */, int cap_nodes);
+ * box in node order (minX,maxX,minY,maxY,minZ,maxZ), plus the root box first.  Every node is
+ * dumped with CRT_BVH_DUMP_WIDTH child entries (the reference topology uses the first two). */
+#define CRT_BVH_DUMP_WIDTH 8
+int crt_bvh_dump(crt_ctx*, int32_t* nnodes, float* root_box6, float* child_boxes /* nnodes*8*6 */,
+                 uint32_t* child_links /* nnodes*8 */, int cap_nodes);
 
 /* ---- render: replaces startRayTracing (Ray.hpp:35, Ray.cu:665-742).  bgr_out is the caller's
  *      width*height*3 buffer, BGR, row 0 = bottom scanline (Ray.cu:724-731). ---- */
@@ -168,7 +171,7 @@ int crt_write_bmp(const char* path, const unsigned char* bgr, int width, int hei
 
 /* Host-only view of the two BVH builders (no device needed): what crt_bvh_build packs and uploads.
  * Two-call pattern: pass NULL arrays to get *nnodes, then arrays with cap_nodes >= *nnodes.
- * child_boxes: nnodes*4*6 floats (minX,maxX,minY,maxY,minZ,maxZ per child); child_links: nnodes*4;
+ * child_boxes: nnodes*8*6 floats (minX,maxX,minY,maxY,minZ,maxZ per child); child_links: nnodes*8;
  * parents: nnodes*2 (parent node, slot in parent); slot_to_scene, rank_of_scene: n each. */
 int crt_host_bvh(const crt_prim* prims, int n, int mode, int32_t* nnodes, int32_t* depth, float* root_box6,
                  float* child_boxes, uint32_t* child_links, uint32_t* parents, uint32_t* slot_to_scene,

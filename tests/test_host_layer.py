@@ -137,7 +137,7 @@ def test_wide_bvh_is_a_valid_hierarchy(crt):
     while stack:
         node, pbox, depth = stack.pop()
         depth_seen = max(depth_seen, depth)
-        for k in range(4):
+        for k in range(links.shape[1]):
             link = int(links[node, k])
             if link == 0xFFFFFFFF:
                 continue
