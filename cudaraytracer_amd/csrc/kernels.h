@@ -33,12 +33,16 @@ constexpr int kFetchChunk = CRT_FETCH_CHUNK;       /* rays a wave takes from the
 constexpr int kFetchStride = 64;       /* uint32 words between the 8 per-region fetch counters (256 B apart) */
 constexpr int kTraceBlock = 256;       /* 4 waves of 64 */
 constexpr int kStackDepth = CRT_STACK_DEPTH;        /* per-lane entries in LDS: stack[depth][lane], conflict-free per wave */
+#ifndef CRT_REFILL8_MIN_IDLE
+#define CRT_REFILL8_MIN_IDLE 24        /* k_trace8: ray set-up is long and runs for the idle lanes only, so refill less often */
+#endif
 #ifndef CRT_TRACE8_MIN_WAVES
-#define CRT_TRACE8_MIN_WAVES 0         /* 0: let the compiler choose; n: __launch_bounds__(256, n) waves per SIMD */
+#define CRT_TRACE8_MIN_WAVES 4         /* __launch_bounds__(256, n): waves per SIMD the register allocation must allow (LDS allows 4) */
 #endif
 #ifndef CRT_STACK_DEPTH8
 #define CRT_STACK_DEPTH8 16
 #endif
+constexpr int kRefillMinIdle8 = CRT_REFILL8_MIN_IDLE;
 constexpr int kStackDepth8 = CRT_STACK_DEPTH8;      /* k_trace8: 64-bit entries, at most one per tree level */
 /* k_trace8 vote: a node step runs when n_node * PRIM_WEIGHT >= n_prim * NODE_WEIGHT */
 #ifndef CRT_VOTE8_PRIM_WEIGHT

@@ -347,62 +347,19 @@ __global__ CRT_TRACE_BOUNDS void k_trace(TraceArgs A, LightsParam LP) {
 /* ------------------------------------------------------------------------------------------
  * k_trace8: traversal of the compressed 8-wide tree (QNode8, layout.h) -- CRT_BVH_WIDE.
  *
- * The 4-wide kernel above is bound by VALU issue (profiles/r01c: SQ_INSTS_VALU = 100 % of the
- * SIMDs' issue slots, ~250 VALU per node visit, 54 visits per ray on the 1M soup).  This kernel
- * spends the instructions differently:
- *   - a plane distance is one v_fma_mix_f32 on an fp16 plane code (no unpack, no convert);
- *   - near/far plane rows are loaded by address (direction sign picks the row), no per-child selects;
+ * The 4-wide quantised kernel of the earlier commits was bound by VALU issue (profiles/r01c:
+ * SQ_INSTS_VALU = 100 % of the SIMDs' issue slots, ~250 VALU per node visit, 54 visits per ray on
+ * the 1M soup).  This kernel spends the instructions differently:
  *   - no distance sort and no per-child stack pushes: a node visit produces an 8-bit hit mask; the
  *     internal hits stay together as ONE 64-bit stack entry (child base | imask | hits permuted
  *     into front-to-back priority by the ray's octant, via a 2 KB LDS table), leaf hits are
  *     tested before descending;
- *   - 8 children per visit roughly halve the number of visits (dependent round trips) per ray.
+ *   - 8 children per visit cut the visits (dependent round trips) per ray from 54 to 38;
+ *   - 80-byte nodes: with half the VALU work the limit became the vector L1's request rate (every
+ *     lane reads its own node: one 16-byte request per clock per CU), so the node is 5 requests.
  * Scheduling (wave vote between node steps and primitive steps, chunked XCD-affine ray fetch,
  * per-lane stack rows in LDS) is the same as in k_trace.
  * ------------------------------------------------------------------------------------------ */
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-
-/* Slab test of child 2j (HI = false) or 2j+1 (HI = true) of a QNode8: the six plane codes are the
- * lower / upper fp16 halves of six words.  A plane distance is ONE v_fma_mix_f32 (fp16 code x fp32
- * scale + fp32 offset); the compiler's own choice for fmaf((float)h, s, b) is v_cvt_f32_f16 +
- * v_pk_fma_f32, and it inserts a canonicalising v_max_f32 x,x after every asm result that feeds
- * fmaxf/fminf -- so the whole ten-instruction sequence is written out here.
- *   tn = max(tnx, tny, tnz, -1.0001e-4)      tf = min(tfx, tfy, tfz, tbest) */
-template <bool HI>
-CRT_DEV bool slab8(uint32_t wnx, uint32_t wfx, uint32_t wny, uint32_t wfy, uint32_t wnz, uint32_t wfz, float sx, float sy,
-                   float sz, float bnx, float bfx, float bny, float bfy, float bnz, float bfz, float tbest) {
-    float tn, tf, t1, t2;
-    if (HI)
-        asm("v_fma_mix_f32 %2, %4, %10, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %6, %11, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %8, %12, %17 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_max_f32 %0, 0xb8d1bc76, %0\n\t"
-            "v_max3_f32 %0, %2, %3, %0\n\t"
-            "v_fma_mix_f32 %2, %5, %10, %14 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %7, %11, %16 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %9, %12, %18 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_min_f32 %1, %1, %19\n\t"
-            "v_min3_f32 %1, %2, %3, %1"
-            : "=&v"(tn), "=&v"(tf), "=&v"(t1), "=&v"(t2)
-            : "v"(wnx), "v"(wfx), "v"(wny), "v"(wfy), "v"(wnz), "v"(wfz), "v"(sx), "v"(sy), "v"(sz), "v"(bnx), "v"(bfx),
-              "v"(bny), "v"(bfy), "v"(bnz), "v"(bfz), "v"(tbest));
-    else
-        asm("v_fma_mix_f32 %2, %4, %10, %13 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %6, %11, %15 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %0, %8, %12, %17 op_sel_hi:[1,0,0]\n\t"
-            "v_max_f32 %0, 0xb8d1bc76, %0\n\t"
-            "v_max3_f32 %0, %2, %3, %0\n\t"
-            "v_fma_mix_f32 %2, %5, %10, %14 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %7, %11, %16 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %1, %9, %12, %18 op_sel_hi:[1,0,0]\n\t"
-            "v_min_f32 %1, %1, %19\n\t"
-            "v_min3_f32 %1, %2, %3, %1"
-            : "=&v"(tn), "=&v"(tf), "=&v"(t1), "=&v"(t2)
-            : "v"(wnx), "v"(wfx), "v"(wny), "v"(wfy), "v"(wnz), "v"(wfz), "v"(sx), "v"(sy), "v"(sz), "v"(bnx), "v"(bfx),
-              "v"(bny), "v"(bfy), "v"(bnz), "v"(bfz), "v"(tbest));
-    return tn <= tf;
-}
-
 #if CRT_TRACE8_MIN_WAVES > 0
 #define CRT_TRACE8_BOUNDS __launch_bounds__(kTraceBlock, CRT_TRACE8_MIN_WAVES)
 #else
@@ -434,7 +391,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
     uint32_t region_k = 0;
     vec3 o, d;
     float ix = 0, iy = 0, iz = 0, anx = 0, afx = 0, any_ = 0, afy = 0, anz = 0, afz = 0;
-    uint32_t R = 0, rowx = kQ8PlaneX, rowy = kQ8PlaneY, rowz = kQ8PlaneZ;
+    uint32_t R = 0;
     float tbest = 0;
     int best = -1;
     uint32_t ray = 0;
@@ -450,7 +407,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
         if (!exhausted) {
             const unsigned long long idle = __ballot(!active);
             const int nidle = __popcll(idle);
-            if (nidle >= kRefillMinIdle) {
+            if (nidle >= kRefillMinIdle8) {
                 if (cnext >= cend) {
                     bool got = false;
                     while (region_k < 8 && !got) {
@@ -498,9 +455,6 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
                             anx = (ngx ? o.x - px : o.x + px) * ix; afx = (ngx ? o.x + px : o.x - px) * ix;
                             any_ = (ngy ? o.y - py : o.y + py) * iy; afy = (ngy ? o.y + py : o.y - py) * iy;
                             anz = (ngz ? o.z - pz : o.z + pz) * iz; afz = (ngz ? o.z + pz : o.z - pz) * iz;
-                            rowx = kQ8PlaneX + (ngx ? 16u : 0u);
-                            rowy = kQ8PlaneY + (ngy ? 16u : 0u);
-                            rowz = kQ8PlaneZ + (ngz ? 16u : 0u);
                             R = (ngx ? 0u : 4u) | (ngy ? 0u : 2u) | (ngz ? 0u : 1u);
                             tbest = 1000000000.0f; best = -1; sp = 0; found = 0; lp = lend = 0; lmask = 0;
                             gbase = 0; gmask = (1u << 8) | (1u << R);      /* a group whose only child is the root */
@@ -546,12 +500,9 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
                         const uint32_t noff = node * (uint32_t)sizeof(QNode8);
                         const uint4 h0 = *reinterpret_cast<const uint4*>(qbase + noff);
                         const uint4 h1 = *reinterpret_cast<const uint4*>(qbase + (noff + 16u));
-                        const uint4 NX = *reinterpret_cast<const uint4*>(qbase + (noff + rowx));
-                        const uint4 FX = *reinterpret_cast<const uint4*>(qbase + (noff + (rowx ^ 16u)));
-                        const uint4 NY = *reinterpret_cast<const uint4*>(qbase + (noff + rowy));
-                        const uint4 FY = *reinterpret_cast<const uint4*>(qbase + (noff + (rowy ^ 16u)));
-                        const uint4 NZ = *reinterpret_cast<const uint4*>(qbase + (noff + rowz));
-                        const uint4 FZ = *reinterpret_cast<const uint4*>(qbase + (noff + (rowz ^ 16u)));
+                        const uint4 PX = *reinterpret_cast<const uint4*>(qbase + (noff + 32u));    /* lo_x[8] hi_x[8] */
+                        const uint4 PY = *reinterpret_cast<const uint4*>(qbase + (noff + 48u));
+                        const uint4 PZ = *reinterpret_cast<const uint4*>(qbase + (noff + 64u));
                         const uint32_t em = h0.w;
                         const float nox = __uint_as_float(h0.x), noy = __uint_as_float(h0.y), noz = __uint_as_float(h0.z);
                         const float sx = __uint_as_float((em << 23) & 0x7f800000u) * ix;
@@ -560,12 +511,28 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
                         const float bnx = fmaf(nox, ix, -anx), bfx = fmaf(nox, ix, -afx);
                         const float bny = fmaf(noy, iy, -any_), bfy = fmaf(noy, iy, -afy);
                         const float bnz = fmaf(noz, iz, -anz), bfz = fmaf(noz, iz, -afz);
+                        /* near / far rows by the sign of the direction: children 0-3 in word 0, 4-7 in word 1 */
+                        const bool ngx = ix < 0.f, ngy = iy < 0.f, ngz = iz < 0.f;
+                        const uint32_t nx0 = ngx ? PX.z : PX.x, nx1 = ngx ? PX.w : PX.y, fx0 = ngx ? PX.x : PX.z, fx1 = ngx ? PX.y : PX.w;
+                        const uint32_t ny0 = ngy ? PY.z : PY.x, ny1 = ngy ? PY.w : PY.y, fy0 = ngy ? PY.x : PY.z, fy1 = ngy ? PY.y : PY.w;
+                        const uint32_t nz0 = ngz ? PZ.z : PZ.x, nz1 = ngz ? PZ.w : PZ.y, fz0 = ngz ? PZ.x : PZ.z, fz1 = ngz ? PZ.y : PZ.w;
                         uint32_t raw = 0;
-#define SLAB8(K, HI, C)                                                                                 \
-    raw |= slab8<HI>(NX.C, FX.C, NY.C, FY.C, NZ.C, FZ.C, sx, sy, sz, bnx, bfx, bny, bfy, bnz, bfz, tbest) ? (1u << (K)) : 0u;
-                        SLAB8(0, false, x) SLAB8(1, true, x) SLAB8(2, false, y) SLAB8(3, true, y)
-                        SLAB8(4, false, z) SLAB8(5, true, z) SLAB8(6, false, w) SLAB8(7, true, w)
+#define QB(W, J) ((float)(((W) >> (8 * (J))) & 0xffu))
+#define SLAB8(K, J, WNX, WFX, WNY, WFY, WNZ, WFZ)                                                \
+    {                                                                                            \
+        const float tnx = fmaf(QB(WNX, J), sx, bnx), tfx = fmaf(QB(WFX, J), sx, bfx);            \
+        const float tny = fmaf(QB(WNY, J), sy, bny), tfy = fmaf(QB(WFY, J), sy, bfy);            \
+        const float tnz = fmaf(QB(WNZ, J), sz, bnz), tfz = fmaf(QB(WFZ, J), sz, bfz);            \
+        const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, -1.0001e-4f));                        \
+        const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tbest));                              \
+        raw |= (tn <= tf) ? (1u << (K)) : 0u;                                                    \
+    }
+                        SLAB8(0, 0, nx0, fx0, ny0, fy0, nz0, fz0) SLAB8(1, 1, nx0, fx0, ny0, fy0, nz0, fz0)
+                        SLAB8(2, 2, nx0, fx0, ny0, fy0, nz0, fz0) SLAB8(3, 3, nx0, fx0, ny0, fy0, nz0, fz0)
+                        SLAB8(4, 0, nx1, fx1, ny1, fy1, nz1, fz1) SLAB8(5, 1, nx1, fx1, ny1, fy1, nz1, fz1)
+                        SLAB8(6, 2, nx1, fx1, ny1, fy1, nz1, fz1) SLAB8(7, 3, nx1, fx1, ny1, fy1, nz1, fz1)
 #undef SLAB8
+#undef QB
                         const uint32_t vmask = h1.x >> 24, imask = em >> 24;
                         raw &= vmask;                       /* an empty slot can pass the padded test of a degenerate node */
                         if (COUNT) { nbox += (unsigned long long)__popc(vmask); nvis++; }
@@ -628,7 +595,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
                 }
                 active = false; lp = lend = 0; lmask = 0;
             }
-        } while (exhausted ? (__ballot(active) != 0ull) : (__popcll(__ballot(active)) > 64 - kRefillMinIdle));
+        } while (exhausted ? (__ballot(active) != 0ull) : (__popcll(__ballot(active)) > 64 - kRefillMinIdle8));
     }
     if (COUNT) {
         atomicAdd(&A.counters[0], nbox);
@@ -672,7 +639,7 @@ void launch_trace(const TraceArgs& a, const LightsParam& lights, int mode, bool 
 }
 
 /* ------------------------------------------------------------------------------------------
- * k_quantize8: Node8 (exact child bounds) -> QNode8.  Plane codes are integers 0..2047 on a
+ * k_quantize8: Node8 (exact child bounds) -> QNode8.  Plane codes are integers 0..255 on a
  * power-of-two grid anchored at the node's own box, rounded outward and checked in double so that
  * every quantised box contains the exact one.  Runs after every build and refit of the wide tree.
  * ------------------------------------------------------------------------------------------ */
@@ -712,8 +679,8 @@ __global__ __launch_bounds__(256) void k_quantize8(const Node8* nodes, uint32_t 
     for (int a = 0; a < 3; a++) {
         const float* clo = a == 0 ? nd.lox : a == 1 ? nd.loy : nd.loz;
         const float* chi = a == 0 ? nd.hix : a == 1 ? nd.hiy : nd.hiz;
-        uint16_t* qlo = a == 0 ? q.lo_x : a == 1 ? q.lo_y : q.lo_z;
-        uint16_t* qhi = a == 0 ? q.hi_x : a == 1 ? q.hi_y : q.hi_z;
+        uint8_t* qlo = a == 0 ? q.lo_x : a == 1 ? q.lo_y : q.lo_z;
+        uint8_t* qhi = a == 0 ? q.hi_x : a == 1 ? q.hi_y : q.hi_z;
         float lo = 3.402823466e+38f, hi = -3.402823466e+38f;
         for (int k = 0; k < 8; k++) if (vmask & (1u << k)) { lo = fminf(lo, clo[k]); hi = fmaxf(hi, chi[k]); }
         const float o = lo <= hi ? lo : 0.f;
@@ -735,8 +702,7 @@ __global__ __launch_bounds__(256) void k_quantize8(const Node8* nodes, uint32_t 
                     while (qh < (uint32_t)kQ8Grid && (double)o + (double)qh * (double)sc < (double)chi[k]) qh++;
                     if ((double)o + (double)ql * (double)sc > (double)clo[k] || (double)o + (double)qh * (double)sc < (double)chi[k]) fits = false;
                 }
-                const _Float16 hl = (_Float16)(float)ql, hh = (_Float16)(float)qh;    /* integers <= 2047 are exact in fp16 */
-                qlo[k] = __builtin_bit_cast(uint16_t, hl); qhi[k] = __builtin_bit_cast(uint16_t, hh);
+                qlo[k] = (uint8_t)ql; qhi[k] = (uint8_t)qh;
             }
             if (fits) break;
             sc *= 2.0f;

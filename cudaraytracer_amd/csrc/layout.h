@@ -6,8 +6,8 @@
  *   nodes   exact child bounds SoA + child links + parent link; master copy for refit and dumps.
  *                            CRT_BVH_REFERENCE: nnodes x 128 B Node4 (two slots used), traversed as is.
  *                            CRT_BVH_WIDE:      nnodes x 256 B Node8.
- *   qnodes  nnodes x 128 B   CRT_BVH_WIDE only: the 8-wide tree compressed for traversal (QNode8):
- *                            node origin + per-axis power-of-two scale, fp16 conservative child
+ *   qnodes  nnodes x  80 B   CRT_BVH_WIDE only: the 8-wide tree compressed for traversal (QNode8):
+ *                            node origin + per-axis power-of-two scale, 8-bit conservative child
  *                            planes, two base indices instead of links.
  *   geom    nprims x  48 B   hit-test record, indexed by SLOT (leaf order of the packed tree)
  *                              triangle: v1.xyz v2.xyz v3.xyz Ng.xyz   (Ng precomputed exactly as Ray.cu:145)
@@ -67,26 +67,26 @@ struct alignas(256) Node8 {
 };
 static_assert(sizeof(Node8) == 256, "Node8 must be 256 bytes");
 
-/* Compressed 8-wide traversal node: one 128-byte line = 8 x 16-byte loads per lane per visit.
- * Child k's box is [o + lo*s, o + hi*s] per axis with s = 2^(e-127); lo/hi are fp16 values that
- * hold integers 0..2047 (exact in fp16), rounded outward, so the box contains the exact one and a
- * plane distance is ONE v_fma_mix_f32 (fp16 x fp32 + fp32) -- no unpack/convert instructions.
- * The six plane rows are separate 16-byte blocks so that a lane loads its ray's NEAR and FAR rows
- * directly (row address picked by the direction sign, far = near ^ 16) instead of selecting per
- * child.  Slots are assigned by octant (slot bit 4/2/1 = child on the +x/+y/+z side of the node
- * centre): visiting hit children in descending (slot ^ R), R = the ray's octant code, is a
- * front-to-back order without computing or sorting distances. */
-struct alignas(128) QNode8 {
+/* Compressed 8-wide traversal node, 80 B = 5 x 16-byte loads per lane per visit.  The traversal
+ * kernel is bound by the vector L1's request rate (one 16-byte lane request per clock per CU when
+ * every lane reads its own node, profiles/r01d), so bytes per visit are what count: an fp16-plane
+ * variant of this node (128 B, 8 requests, one v_fma_mix_f32 per plane) ran the same VALU count
+ * 1.3x slower.  Child k's box is [o + lo*s, o + hi*s] per axis with s = 2^(e-127) and 8-bit plane
+ * codes rounded outward, so the box contains the exact one.  Each 16-byte plane block holds the lo
+ * and the hi row of one axis, so every byte loaded is used; near/far rows are picked by the sign of
+ * the ray direction.  Slots are assigned by octant (slot bit 4/2/1 = child on the +x/+y/+z side of
+ * the node centre): visiting hit children in descending (slot ^ R), R = the ray's octant code, is
+ * a front-to-back order without computing or sorting distances. */
+struct alignas(16) QNode8 {
     float ox, oy, oz;
     uint32_t exps_imask;      /* ex | ey << 8 | ez << 16 | imask << 24; imask bit k: child k is a node */
     uint32_t base_vmask;      /* first internal child (node index, < 2^24) | vmask << 24; vmask bit k: child k exists */
     uint32_t prim_base;       /* first slot of this node's leaf primitives */
     uint8_t meta[8];          /* leaf child k: 0x80 | (count-1) << 5 | (first slot - prim_base); else 0 */
-    uint16_t lo_x[8], hi_x[8], lo_y[8], hi_y[8], lo_z[8], hi_z[8];
+    uint8_t lo_x[8], hi_x[8], lo_y[8], hi_y[8], lo_z[8], hi_z[8];
 };
-static_assert(sizeof(QNode8) == 128, "QNode8 must be 128 bytes");
-constexpr uint32_t kQ8PlaneX = 32, kQ8PlaneY = 64, kQ8PlaneZ = 96;   /* byte offsets of the lo rows; hi = lo + 16 */
-constexpr int kQ8Grid = 2047;           /* largest integer stored in a plane */
+static_assert(sizeof(QNode8) == 80, "QNode8 must be 80 bytes");
+constexpr int kQ8Grid = 255;            /* largest plane code */
 constexpr int kWide8LeafMax = 4;        /* primitives per leaf of the wide tree (2 bits in meta) */
 
 struct alignas(16) Geom { float w[12]; };
