@@ -306,13 +306,13 @@ crt_ctx* crt_create(int device, int* err) {
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void**)&c->d_status, 4) != hipSuccess ||
-        hipMalloc((void**)&c->d_testctr, 8 * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc((void**)&c->d_testctr, 32 * sizeof(unsigned long long)) != hipSuccess) {
         if (err) *err = CRT_ERR_HIP;
         delete c;
         return nullptr;
     }
     hipMemset(c->d_status, 0, 4);
-    hipMemset(c->d_testctr, 0, 8 * sizeof(unsigned long long));
+    hipMemset(c->d_testctr, 0, 32 * sizeof(unsigned long long));
     c->grid_blocks = trace_grid_blocks(device);
     if (err) *err = CRT_OK;
     return c;
@@ -595,7 +595,7 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
     if (rc) return rc;
     c->h_ctr.assign((size_t)spp * kCtrStride, 0);
     HIPCHECK(c, hipMemsetAsync(c->d_ctr, 0, (size_t)spp * kCtrStride * 4, c->stream));
-    if (c->counting) HIPCHECK(c, hipMemsetAsync(c->d_testctr, 0, 8 * sizeof(unsigned long long), c->stream));
+    if (c->counting) HIPCHECK(c, hipMemsetAsync(c->d_testctr, 0, 32 * sizeof(unsigned long long), c->stream));
     if (c->capture) {
         HIPCHECK(c, hipMemsetD32Async((hipDeviceptr_t)c->cap_ids, -9, (size_t)p->bounces * npix, c->stream));
         HIPCHECK(c, hipMemsetD32Async((hipDeviceptr_t)c->cap_ts, 0, (size_t)p->bounces * npix, c->stream));
@@ -632,7 +632,7 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
             if (c->lights.n > 0) {
                 TraceArgs ts = ta;
                 ts.rayO = c->shO; ts.rayD = c->shD; ts.count = ctr + 16 + b; ts.next = ctr + kCtrFetch0 + (2 * b + 1) * 8 * kFetchStride;
-                ts.hitSlot = nullptr; ts.hitT = nullptr; ts.shflag = c->shflag; ts.counters = c->d_testctr + 4;
+                ts.hitSlot = nullptr; ts.hitT = nullptr; ts.shflag = c->shflag; ts.counters = c->d_testctr + 16;
                 launch_trace(ts, c->lights, TRACE_SHADOW, c->counting, c->hdr.mode == CRT_BVH_WIDE, c->grid_blocks, c->stream);
                 mark(c, EV_TRACE_S);
             }
@@ -680,11 +680,16 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
     hipEventElapsedTime(&tot, c->evpool[c->evlog.front().second], c->evpool[c->evlog.back().second]);
     st.ms_total = tot;
     if (c->counting) {
-        unsigned long long t[8];
+        unsigned long long t[32];
         HIPCHECK(c, hipMemcpy(t, c->d_testctr, sizeof t, hipMemcpyDeviceToHost));
-        st.box_tests = t[0]; st.tri_tests = t[1]; st.sph_tests = t[2];
-        st.node_visits = t[3];
-        st.box_tests_shadow = t[4]; st.tri_tests_shadow = t[5]; st.sph_tests_shadow = t[6]; st.node_visits_shadow = t[7];
+        if (getenv("CRT_DEBUG_SCHED"))      /* wave scheduling statistics of k_trace8 */
+            for (int m = 0; m < 2; m++) {
+                const unsigned long long* q = t + 16 * m + 8;
+                fprintf(stderr, "[crt sched %s] node iterations %llu (%.1f lanes served), prim iterations %llu (%.1f lanes served), active lanes per iteration %.1f\n",
+                        m ? "shadow" : "nearest", q[0], q[0] ? (double)q[1] / q[0] : 0., q[2], q[2] ? (double)q[3] / q[2] : 0., (q[0] + q[2]) ? (double)q[4] / (q[0] + q[2]) : 0.);
+            }
+        st.box_tests = t[0]; st.tri_tests = t[1]; st.sph_tests = t[2]; st.node_visits = t[3];
+        st.box_tests_shadow = t[16]; st.tri_tests_shadow = t[17]; st.sph_tests_shadow = t[18]; st.node_visits_shadow = t[19];
     }
     c->last_w = p->width; c->last_h = p->height; c->last_bounces = p->bounces;
     return CRT_OK;
@@ -741,7 +746,7 @@ static int trace_hook(crt_ctx* c, const float* org_dir, int n, int32_t* prim_out
         ta.sv = view_of(c); ta.rayO = d_o; ta.rayD = d_d; ta.count = d_cnt; ta.next = d_cnt + 64;
         ta.hitSlot = d_slot; ta.hitT = d_t; ta.shflag = d_flag; ta.scene_abs = c->scene_abs;
         ta.ovf = c->d_ovf; ta.ovf_depth = c->ovf_depth; ta.counters = c->d_testctr; ta.status = c->d_status;
-        if (c->counting) TH(hipMemsetAsync(c->d_testctr, 0, 8 * sizeof(unsigned long long), c->stream));
+        if (c->counting) TH(hipMemsetAsync(c->d_testctr, 0, 32 * sizeof(unsigned long long), c->stream));
         LightsParam dummy{}; dummy.n = 1;          /* light 0 directional: the Ray.cu:650-656 predicate */
         hipEvent_t e0 = next_event(c), e1 = next_event(c);
         c->evused -= 2;

@@ -34,7 +34,7 @@ constexpr int kFetchStride = 64;       /* uint32 words between the 8 per-region 
 constexpr int kTraceBlock = 256;       /* 4 waves of 64 */
 constexpr int kStackDepth = CRT_STACK_DEPTH;        /* per-lane entries in LDS: stack[depth][lane], conflict-free per wave */
 #ifndef CRT_REFILL8_MIN_IDLE
-#define CRT_REFILL8_MIN_IDLE 24        /* k_trace8: ray set-up is long and runs for the idle lanes only, so refill less often */
+#define CRT_REFILL8_MIN_IDLE 12        /* k_trace8: a refill stalls the wave for a load round trip and runs the ray set-up for the idle lanes only */
 #endif
 #ifndef CRT_TRACE8_MIN_WAVES
 #define CRT_TRACE8_MIN_WAVES 4         /* __launch_bounds__(256, n): waves per SIMD the register allocation must allow (LDS allows 4) */

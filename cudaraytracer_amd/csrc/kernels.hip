@@ -360,6 +360,57 @@ __global__ CRT_TRACE_BOUNDS void k_trace(TraceArgs A, LightsParam LP) {
  * Scheduling (wave vote between node steps and primitive steps, chunked XCD-affine ray fetch,
  * per-lane stack rows in LDS) is the same as in k_trace.
  * ------------------------------------------------------------------------------------------ */
+/* Slab test of one child of a QNode8.  The six plane codes arrive as fp16 values 1024 + q -- the
+ * byte q under the constant high byte 0x64, two codes per word, assembled by ONE v_perm_b32 per
+ * word -- so a plane distance is ONE v_fma_mix_f32 (fp16 x fp32 + fp32) instead of
+ * v_cvt_f32_ubyte + v_fma_f32; the node origin is stored shifted by -1024 s to match.  HI picks the
+ * upper half of the words.  The whole ten-instruction sequence is written out because the
+ * compiler canonicalises (v_max_f32 x,x) every asm result that feeds fmaxf/fminf.
+ *   tn = max(tnx, tny, tnz, -1.0001e-4)      tf = min(tfx, tfy, tfz, tbest)      raw = 2 raw + (tn <= tf)
+ * (v_addc_co_u32 shifts the hit bit in through the per-lane carry: children are tested 7 .. 0). */
+template <bool HI>
+CRT_DEV void slab8(uint32_t& raw, uint32_t wnx, uint32_t wfx, uint32_t wny, uint32_t wfy, uint32_t wnz, uint32_t wfz, float sx,
+                   float sy, float sz, float bnx, float bfx, float bny, float bfy, float bnz, float bfz, float tbest) {
+    float tn, tf, t1, t2;
+#define SLAB8_OPERANDS                                                                                                   \
+    : [tn] "=&v"(tn), [tf] "=&v"(tf), [t1] "=&v"(t1), [t2] "=&v"(t2), [raw] "+v"(raw)                                    \
+    : [wnx] "v"(wnx), [wfx] "v"(wfx), [wny] "v"(wny), [wfy] "v"(wfy), [wnz] "v"(wnz), [wfz] "v"(wfz), [sx] "v"(sx),      \
+      [sy] "v"(sy), [sz] "v"(sz), [bnx] "v"(bnx), [bfx] "v"(bfx), [bny] "v"(bny), [bfy] "v"(bfy), [bnz] "v"(bnz),        \
+      [bfz] "v"(bfz), [tb] "v"(tbest)                                                                                    \
+    : "vcc"
+    if (HI)
+        asm(
+            "v_fma_mix_f32 %[t1], %[wnx], %[sx], %[bnx] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[t2], %[wny], %[sy], %[bny] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[tn], %[wnz], %[sz], %[bnz] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_max_f32 %[tn], 0xb8d1bc76, %[tn]\n\t"
+            "v_max3_f32 %[tn], %[t1], %[t2], %[tn]\n\t"
+            "v_fma_mix_f32 %[t1], %[wfx], %[sx], %[bfx] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[t2], %[wfy], %[sy], %[bfy] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[tf], %[wfz], %[sz], %[bfz] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_min_f32 %[tf], %[tf], %[tb]\n\t"
+            "v_min3_f32 %[tf], %[t1], %[t2], %[tf]\n\t"
+            "v_cmp_le_f32 vcc, %[tn], %[tf]\n\t"
+            "v_addc_co_u32 %[raw], vcc, %[raw], %[raw], vcc"
+            SLAB8_OPERANDS);
+    else
+        asm(
+            "v_fma_mix_f32 %[t1], %[wnx], %[sx], %[bnx] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[t2], %[wny], %[sy], %[bny] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[tn], %[wnz], %[sz], %[bnz] op_sel_hi:[1,0,0]\n\t"
+            "v_max_f32 %[tn], 0xb8d1bc76, %[tn]\n\t"
+            "v_max3_f32 %[tn], %[t1], %[t2], %[tn]\n\t"
+            "v_fma_mix_f32 %[t1], %[wfx], %[sx], %[bfx] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[t2], %[wfy], %[sy], %[bfy] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %[tf], %[wfz], %[sz], %[bfz] op_sel_hi:[1,0,0]\n\t"
+            "v_min_f32 %[tf], %[tf], %[tb]\n\t"
+            "v_min3_f32 %[tf], %[t1], %[t2], %[tf]\n\t"
+            "v_cmp_le_f32 vcc, %[tn], %[tf]\n\t"
+            "v_addc_co_u32 %[raw], vcc, %[raw], %[raw], vcc"
+            SLAB8_OPERANDS);
+#undef SLAB8_OPERANDS
+}
+
 #if CRT_TRACE8_MIN_WAVES > 0
 #define CRT_TRACE8_BOUNDS __launch_bounds__(kTraceBlock, CRT_TRACE8_MIN_WAVES)
 #else
@@ -402,6 +453,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
     int found = 0;
     int lightj = 0;
     unsigned long long nbox = 0, ntri = 0, nsph = 0, nvis = 0;
+    unsigned long long sch[5] = {0, 0, 0, 0, 0};
 
     for (;;) {
         if (!exhausted) {
@@ -441,7 +493,9 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
                             ray = idx;
                             o = vec3(ro.x, ro.y, ro.z); d = vec3(rd.x, rd.y, rd.z);
                             if (MODE == TRACE_SHADOW) { ray = __float_as_uint(ro.w); lightj = (int)__float_as_uint(rd.w); }
-                            float rx = 1.0f / d.x, ry = 1.0f / d.y, rz = 1.0f / d.z;
+                            /* v_rcp_f32 (1 ulp) instead of an IEEE division: the box test only has to be
+                             * conservative and the pad below is 1e4 times that error */
+                            float rx = __builtin_amdgcn_rcpf(d.x), ry = __builtin_amdgcn_rcpf(d.y), rz = __builtin_amdgcn_rcpf(d.z);
                             if (!(fabsf(d.x) > 1e-20f)) rx = copysignf(1e20f, d.x);
                             if (!(fabsf(d.y) > 1e-20f)) ry = copysignf(1e20f, d.y);
                             if (!(fabsf(d.z) > 1e-20f)) rz = copysignf(1e20f, d.z);
@@ -472,6 +526,10 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
             const int n_node = __popcll(__ballot(want_node));
             const int n_prim = __popcll(__ballot(want_prim));
             bool finish = false;
+            if (COUNT && lane == 0) {     /* scheduling statistics: [8] node iterations [9] lanes served [10] prim iterations [11] lanes served [12] active lanes */
+                if (n_node * CRT_VOTE8_PRIM_WEIGHT >= n_prim * CRT_VOTE8_NODE_WEIGHT) { sch[0]++; sch[1] += n_node; } else { sch[2]++; sch[3] += n_prim; }
+                sch[4] += n_node + n_prim;
+            }
             if (n_node * CRT_VOTE8_PRIM_WEIGHT >= n_prim * CRT_VOTE8_NODE_WEIGHT) {
                 if (want_node) {
                     if ((gmask & 0xffu) == 0u) {
@@ -497,12 +555,10 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
                             sp++;
                         }
                         /* 32-bit byte offsets from the uniform base (nodes < 2^24): scalar base + vector offset addressing */
-                        const uint32_t noff = node * (uint32_t)sizeof(QNode8);
-                        const uint4 h0 = *reinterpret_cast<const uint4*>(qbase + noff);
-                        const uint4 h1 = *reinterpret_cast<const uint4*>(qbase + (noff + 16u));
-                        const uint4 PX = *reinterpret_cast<const uint4*>(qbase + (noff + 32u));    /* lo_x[8] hi_x[8] */
-                        const uint4 PY = *reinterpret_cast<const uint4*>(qbase + (noff + 48u));
-                        const uint4 PZ = *reinterpret_cast<const uint4*>(qbase + (noff + 64u));
+                        static_assert(sizeof(QNode8) == 80, "node * 80 below");
+                        const uint4* np = reinterpret_cast<const uint4*>(qbase + ((node << 6) + (node << 4)));
+                        const uint4 h0 = np[0], h1 = np[1];
+                        const uint4 PX = np[2], PY = np[3], PZ = np[4];       /* lo_x[8] hi_x[8] | lo_y hi_y | lo_z hi_z */
                         const uint32_t em = h0.w;
                         const float nox = __uint_as_float(h0.x), noy = __uint_as_float(h0.y), noz = __uint_as_float(h0.z);
                         const float sx = __uint_as_float((em << 23) & 0x7f800000u) * ix;
@@ -517,22 +573,24 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
                         const uint32_t ny0 = ngy ? PY.z : PY.x, ny1 = ngy ? PY.w : PY.y, fy0 = ngy ? PY.x : PY.z, fy1 = ngy ? PY.y : PY.w;
                         const uint32_t nz0 = ngz ? PZ.z : PZ.x, nz1 = ngz ? PZ.w : PZ.y, fz0 = ngz ? PZ.x : PZ.z, fz1 = ngz ? PZ.y : PZ.w;
                         uint32_t raw = 0;
-#define QB(W, J) ((float)(((W) >> (8 * (J))) & 0xffu))
-#define SLAB8(K, J, WNX, WFX, WNY, WFY, WNZ, WFZ)                                                \
-    {                                                                                            \
-        const float tnx = fmaf(QB(WNX, J), sx, bnx), tfx = fmaf(QB(WFX, J), sx, bfx);            \
-        const float tny = fmaf(QB(WNY, J), sy, bny), tfy = fmaf(QB(WFY, J), sy, bfy);            \
-        const float tnz = fmaf(QB(WNZ, J), sz, bnz), tfz = fmaf(QB(WFZ, J), sz, bfz);            \
-        const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, -1.0001e-4f));                        \
-        const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tbest));                              \
-        raw |= (tn <= tf) ? (1u << (K)) : 0u;                                                    \
+                        /* bytes (q_a, q_b) of a row word -> fp16 pair (1024 + q_a, 1024 + q_b): byte 4 of the
+                         * v_perm source is the constant 0x64 */
+#define PAIR01(W) __builtin_amdgcn_perm(0x64646464u, (W), 0x04010400u)
+#define PAIR23(W) __builtin_amdgcn_perm(0x64646464u, (W), 0x04030402u)
+#define SLAB8x4(NXW, FXW, NYW, FYW, NZW, FZW)                                                                 \
+    {                                                                                                         \
+        const uint32_t c0 = PAIR23(NXW), c1 = PAIR23(FXW), c2 = PAIR23(NYW), c3 = PAIR23(FYW), c4 = PAIR23(NZW), c5 = PAIR23(FZW); \
+        slab8<true>(raw, c0, c1, c2, c3, c4, c5, sx, sy, sz, bnx, bfx, bny, bfy, bnz, bfz, tbest);            \
+        slab8<false>(raw, c0, c1, c2, c3, c4, c5, sx, sy, sz, bnx, bfx, bny, bfy, bnz, bfz, tbest);           \
+        const uint32_t a0 = PAIR01(NXW), a1 = PAIR01(FXW), a2 = PAIR01(NYW), a3 = PAIR01(FYW), a4 = PAIR01(NZW), a5 = PAIR01(FZW); \
+        slab8<true>(raw, a0, a1, a2, a3, a4, a5, sx, sy, sz, bnx, bfx, bny, bfy, bnz, bfz, tbest);            \
+        slab8<false>(raw, a0, a1, a2, a3, a4, a5, sx, sy, sz, bnx, bfx, bny, bfy, bnz, bfz, tbest);           \
     }
-                        SLAB8(0, 0, nx0, fx0, ny0, fy0, nz0, fz0) SLAB8(1, 1, nx0, fx0, ny0, fy0, nz0, fz0)
-                        SLAB8(2, 2, nx0, fx0, ny0, fy0, nz0, fz0) SLAB8(3, 3, nx0, fx0, ny0, fy0, nz0, fz0)
-                        SLAB8(4, 0, nx1, fx1, ny1, fy1, nz1, fz1) SLAB8(5, 1, nx1, fx1, ny1, fy1, nz1, fz1)
-                        SLAB8(6, 2, nx1, fx1, ny1, fy1, nz1, fz1) SLAB8(7, 3, nx1, fx1, ny1, fy1, nz1, fz1)
-#undef SLAB8
-#undef QB
+                        SLAB8x4(nx1, fx1, ny1, fy1, nz1, fz1)      /* children 7, 6, 5, 4 */
+                        SLAB8x4(nx0, fx0, ny0, fy0, nz0, fz0)      /* children 3, 2, 1, 0 */
+#undef SLAB8x4
+#undef PAIR01
+#undef PAIR23
                         const uint32_t vmask = h1.x >> 24, imask = em >> 24;
                         raw &= vmask;                       /* an empty slot can pass the padded test of a degenerate node */
                         if (COUNT) { nbox += (unsigned long long)__popc(vmask); nvis++; }
@@ -602,6 +660,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
         atomicAdd(&A.counters[1], ntri);
         atomicAdd(&A.counters[2], nsph);
         atomicAdd(&A.counters[3], nvis);
+        if (lane == 0) for (int i = 0; i < 5; i++) atomicAdd(&A.counters[8 + i], sch[i]);
     }
 }
 
@@ -690,17 +749,24 @@ __global__ __launch_bounds__(256) void k_quantize8(const Node8* nodes, uint32_t 
         (void)frexpf(ext / (float)(kQ8Grid - 1), &e);
         float sc = ldexpf(1.0f, e);
         if (!(ext > 0.f)) sc = ldexpf(1.0f, -60);
+        /* the traversal reads a code q as the fp16 value 1024 + q (slab8 above), so the stored origin
+         * is os = o - 1024 s and a plane sits at os + (1024 + q) s; the containment check uses exactly that */
+        float os = o;
         for (int attempt = 0; attempt < 4; attempt++) {
             bool fits = true;
+            os = o - (float)kQ8Bias * sc;
+            /* round the shifted origin DOWN: code 0 must not lie above the node's own lower bound */
+            if ((double)os + (double)kQ8Bias * (double)sc > (double)o) os = __uint_as_float(os > 0.f ? __float_as_uint(os) - 1u : (os < 0.f ? __float_as_uint(os) + 1u : 0x80000001u));
             for (int k = 0; k < 8; k++) {
                 uint32_t ql = (uint32_t)kQ8Grid, qh = 0;       /* empty slot: inverted */
                 if (vmask & (1u << k)) {
                     float fl = floorf((clo[k] - o) / sc), fh = ceilf((chi[k] - o) / sc);
                     fl = fminf(fmaxf(fl, 0.f), (float)kQ8Grid); fh = fminf(fmaxf(fh, 0.f), (float)kQ8Grid);
                     ql = (uint32_t)fl; qh = (uint32_t)fh;
-                    while (ql > 0 && (double)o + (double)ql * (double)sc > (double)clo[k]) ql--;
-                    while (qh < (uint32_t)kQ8Grid && (double)o + (double)qh * (double)sc < (double)chi[k]) qh++;
-                    if ((double)o + (double)ql * (double)sc > (double)clo[k] || (double)o + (double)qh * (double)sc < (double)chi[k]) fits = false;
+                    while (ql > 0 && (double)os + (double)(kQ8Bias + ql) * (double)sc > (double)clo[k]) ql--;
+                    while (qh < (uint32_t)kQ8Grid && (double)os + (double)(kQ8Bias + qh) * (double)sc < (double)chi[k]) qh++;
+                    if ((double)os + (double)(kQ8Bias + ql) * (double)sc > (double)clo[k] ||
+                        (double)os + (double)(kQ8Bias + qh) * (double)sc < (double)chi[k]) fits = false;
                 }
                 qlo[k] = (uint8_t)ql; qhi[k] = (uint8_t)qh;
             }
@@ -708,7 +774,7 @@ __global__ __launch_bounds__(256) void k_quantize8(const Node8* nodes, uint32_t 
             sc *= 2.0f;
         }
         ex[a] = (__float_as_uint(sc) >> 23) & 0xffu;
-        org[a] = o;
+        org[a] = os;
     }
     q.ox = org[0]; q.oy = org[1]; q.oz = org[2];
     q.exps_imask = ex[0] | (ex[1] << 8) | (ex[2] << 16) | (imask << 24);

@@ -70,8 +70,8 @@ static_assert(sizeof(Node8) == 256, "Node8 must be 256 bytes");
 /* Compressed 8-wide traversal node, 80 B = 5 x 16-byte loads per lane per visit.  The traversal
  * kernel is bound by the vector L1's request rate (one 16-byte lane request per clock per CU when
  * every lane reads its own node, profiles/r01d), so bytes per visit are what count: an fp16-plane
- * variant of this node (128 B, 8 requests, one v_fma_mix_f32 per plane) ran the same VALU count
- * 1.3x slower.  Child k's box is [o + lo*s, o + hi*s] per axis with s = 2^(e-127) and 8-bit plane
+ * variant of this node (128 B, 8 requests) was slower with fewer instructions.  Child k's box is
+ * [o + lo*s, o + hi*s] per axis with s = 2^(e-127) and 8-bit plane
  * codes rounded outward, so the box contains the exact one.  Each 16-byte plane block holds the lo
  * and the hi row of one axis, so every byte loaded is used; near/far rows are picked by the sign of
  * the ray direction.  Slots are assigned by octant (slot bit 4/2/1 = child on the +x/+y/+z side of
@@ -87,6 +87,7 @@ struct alignas(16) QNode8 {
 };
 static_assert(sizeof(QNode8) == 80, "QNode8 must be 80 bytes");
 constexpr int kQ8Grid = 255;            /* largest plane code */
+constexpr uint32_t kQ8Bias = 1024;      /* a code q is read as the fp16 value 1024 + q (bits 0x6400 | q): ox/oy/oz hold o - 1024 s */
 constexpr int kWide8LeafMax = 4;        /* primitives per leaf of the wide tree (2 bits in meta) */
 
 struct alignas(16) Geom { float w[12]; };
