@@ -69,7 +69,7 @@ def cpu_baseline(prims, lights, cam, tgt, width, height, bounces, max_threads):
     st = sc.stats(reset=True)
     sc.close()
     return {
-        "value": round(st["traversals"] / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+        "value": round(st["traversals"] / dt / 1e6, 6), "unit": "Mrays/s", "cores": cores, "kind": "port",
         "sample": f"centred {rect[2] - rect[0]}x{rect[3] - rect[1]} sub-rectangle of the {width}x{height} frame, "
                   f"bounces={bounces}: {st['traversals']} traversals issued by the reference's logic "
                   f"({st['live_traversals']} on live paths) in {dt:.2f} s, "
@@ -190,6 +190,16 @@ def main():
         sh_launches = max(1, acc["launches_trace_shadow"])
         sh_avg_ms = acc["ms_trace_shadow"] / sh_launches
         sh_achieved = (bytes_shadow / max(1, cst["launches_trace_shadow"])) / (sh_avg_ms * 1e-3) / 1e9 if sh_avg_ms > 0 else 0.0
+        # HBM-side bytes per launch of the same kernel from the committed PMC passes (rocprofv3 cannot be
+        # nested inside this process): only quoted for the default workload those passes measured
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
+        default_workload = (a.tris, a.width, a.height, a.bounces, a.spp, a.bvh, world) == (1000000, 3840, 2160, 3, 1, 0, 1)
+        if default_workload and os.path.exists(tpath):
+            try:
+                traffic = float(json.load(open(tpath))["hbm_bytes_per_launch"])
+            except Exception:
+                traffic = None
         out = {
             "metric": "Mrays/sec (primary+shadow+reflect), 1M-tri 4K scene",
             "value": round(total_rays * a.steps / elapsed / 1e6, 3),
@@ -216,17 +226,17 @@ def main():
                 "bvh_build_host_ms": round(cst["ms_build_host"], 1),
             },
             "roofline": {
-                "kernel": "k_trace<NEAREST>", "bound": "hbm",
+                "kernel": "k_trace8<NEAREST>" if a.bvh == 0 else "k_trace<NEAREST>", "bound": "hbm",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
+                "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(per_launch_bytes), "avg_launch_ms": round(avg_ms, 4),
                 "launches_timed": acc["launches_trace_nearest"],
                 "per_ray": {"node_visits": round(cst["node_visits"] / max(1, n_near), 2),
                             "box_tests": round(cst["box_tests"] / max(1, n_near), 2),
                             "tri_tests": round(cst["tri_tests"] / max(1, n_near), 2),
                             "bytes": round(bytes_near / max(1, n_near), 1)},
-                "shadow_kernel": {"kernel": "k_trace<SHADOW>", "achieved": round(sh_achieved, 2),
+                "shadow_kernel": {"kernel": "k_trace8<SHADOW>" if a.bvh == 0 else "k_trace<SHADOW>", "achieved": round(sh_achieved, 2),
                                   "frac": round(sh_achieved / HBM_PEAK_GBS, 5), "avg_launch_ms": round(sh_avg_ms, 4),
                                   "per_ray_node_visits": round(cst["node_visits_shadow"] / max(1, cst["rays_shadow"]), 2),
                                   "per_ray_box_tests": round(cst["box_tests_shadow"] / max(1, cst["rays_shadow"]), 2),
