@@ -63,7 +63,7 @@ class Stats(C.Structure):
 # every symbol include/crt.h declares; tests/test_abi.py checks the library exports all of them
 ABI_SYMBOLS = [
     "crt_create", "crt_destroy", "crt_last_error", "crt_params_default", "crt_set_counting",
-    "crt_scene_set", "crt_scene_update", "crt_lights_set",
+    "crt_scene_set", "crt_scene_update", "crt_lights_set", "crt_animate_device", "crt_scene_get",
     "crt_bvh_build", "crt_bvh_refit", "crt_bvh_free", "crt_bvh_reference_order", "crt_bvh_dump",
     "crt_render", "crt_render_device", "crt_set_capture", "crt_get_capture", "crt_get_color",
     "crt_trace", "crt_trace_shadow",
@@ -88,6 +88,7 @@ lib.crt_camera_default.argtypes = [C.POINTER(Camera)]
 for _name, _args in {
     "crt_set_counting": [_vp, _i], "crt_set_capture": [_vp, _i],
     "crt_scene_set": [_vp, _vp, _i], "crt_scene_update": [_vp, _vp, _i], "crt_lights_set": [_vp, _vp, _i],
+    "crt_animate_device": [_vp], "crt_scene_get": [_vp, _vp, _i],
     "crt_bvh_build": [_vp, _i], "crt_bvh_refit": [_vp, _i], "crt_bvh_free": [_vp],
     "crt_bvh_reference_order": [_vp, _vp, _i], "crt_bvh_dump": [_vp, _vp, _vp, _vp, _vp, _i],
     "crt_render": [_vp, C.POINTER(Camera), C.POINTER(Params), _vp],
@@ -267,6 +268,14 @@ class Context:
     def update_scene(self, prims):
         prims = np.ascontiguousarray(prims, PRIM_DTYPE)
         self._ck(lib.crt_scene_update(self.h, _ptr(prims), len(prims)))
+
+    def animate_device(self):
+        self._ck(lib.crt_animate_device(self.h))
+
+    def get_scene(self):
+        out = np.zeros(self.nprims, PRIM_DTYPE)
+        self._ck(lib.crt_scene_get(self.h, _ptr(out), self.nprims))
+        return out
 
     def set_lights(self, lights):
         lights = np.ascontiguousarray(lights, LIGHT_DTYPE)

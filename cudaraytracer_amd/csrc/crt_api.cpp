@@ -48,6 +48,7 @@ struct crt_ctx {
     RefTree ref;
     HostBVH bvh;
     bool built = false, have_ref = false, imported = false;
+    bool host_stale = false;     /* crt_animate_device moved the device copy of the scene past c->prims */
 
     /* packed scene */
     void* d_blob = nullptr; size_t blob_bytes = 0; size_t blob_cap = 0;
@@ -352,7 +353,7 @@ int crt_scene_set(crt_ctx* c, const crt_prim* prims, int n) {
     HIPCHECK(c, hipSetDevice(c->device));
     c->prims.assign(prims, prims + n);
     dedupe_materials(c);
-    c->built = false; c->have_ref = false; c->imported = false;
+    c->built = false; c->have_ref = false; c->imported = false; c->host_stale = false;
     return upload_prims(c);
 }
 
@@ -363,6 +364,7 @@ int crt_scene_update(crt_ctx* c, const crt_prim* prims, int n) {
     for (int i = 0; i < n; i++)
         if (prims[i].type != c->prims[i].type) return fail(c, CRT_ERR_ARG, "crt_scene_update: primitive type changed");
     HIPCHECK(c, hipSetDevice(c->device));
+    c->host_stale = false;
     /* materials keep their ids: only geometry (and normals) move, main.cu:545-573 */
     for (int i = 0; i < n; i++) {
         crt_prim& d = c->prims[i]; const crt_prim& s = prims[i];
@@ -382,6 +384,38 @@ int crt_scene_update(crt_ctx* c, const crt_prim* prims, int n) {
     return CRT_OK;
 }
 
+int crt_animate_device(crt_ctx* c) {
+    if (!c) return CRT_ERR_ARG;
+    if (c->imported) return fail(c, CRT_ERR_STATE, "crt_animate_device: scene was imported as a blob; set it with crt_scene_set first");
+    HIPCHECK(c, hipSetDevice(c->device));
+    const uint32_t n = (uint32_t)c->prims.size();
+    AnimParam a;
+    animation_matrix(a.m);
+    launch_animate(c->d_prims, n, a, c->stream);
+    if (c->built) {
+        char* b = (char*)c->d_blob;
+        launch_pack_prims(c->d_prims, c->d_matid, (const uint32_t*)(b + c->hdr.off_slot_of), n,
+                          (Geom*)(b + c->hdr.off_geom), (Shade*)(b + c->hdr.off_shade), c->stream);
+    }
+    HIPCHECK(c, hipGetLastError());
+    c->host_stale = n > 0;
+    return CRT_OK;
+}
+
+int crt_scene_get(crt_ctx* c, crt_prim* prims_out, int n) {
+    if (!c || !prims_out) return CRT_ERR_ARG;
+    if (c->imported) return fail(c, CRT_ERR_STATE, "crt_scene_get: scene was imported as a blob");
+    if ((size_t)n != c->prims.size()) return fail(c, CRT_ERR_ARG, "crt_scene_get: count differs from crt_scene_set");
+    HIPCHECK(c, hipSetDevice(c->device));
+    if (c->host_stale) {
+        HIPCHECK(c, hipMemcpyAsync(c->prims.data(), c->d_prims, (size_t)n * sizeof(crt_prim), hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(c, hipStreamSynchronize(c->stream));
+        c->host_stale = false;
+    }
+    memcpy(prims_out, c->prims.data(), (size_t)n * sizeof(crt_prim));
+    return CRT_OK;
+}
+
 int crt_lights_set(crt_ctx* c, const crt_light* lights, int n) {
     if (!c || n < 0 || n > CRT_MAX_LIGHTS || (n > 0 && !lights)) return fail(c, CRT_ERR_ARG, "crt_lights_set: 0..CRT_MAX_LIGHTS lights");
     memset(&c->lights, 0, sizeof c->lights);
@@ -396,6 +430,11 @@ int crt_bvh_build(crt_ctx* c, int mode) {
     if (c->imported) return fail(c, CRT_ERR_STATE, "crt_bvh_build: scene was imported as a blob");
     HIPCHECK(c, hipSetDevice(c->device));
     const int n = (int)c->prims.size();
+    if (c->host_stale) {          /* the scene was animated on the device: the host builders need its current state */
+        HIPCHECK(c, hipMemcpyAsync(c->prims.data(), c->d_prims, (size_t)n * sizeof(crt_prim), hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(c, hipStreamSynchronize(c->stream));
+        c->host_stale = false;
+    }
     auto t0 = std::chrono::steady_clock::now();
     int rc = build_reference_tree(c->prims.data(), n, c->ref);
     if (rc) return fail(c, rc, "BVH build: reference split does not terminate (more than 64 primitives share a centroid)");

@@ -108,6 +108,9 @@ void launch_shade(const FrameParams& fp, const FrameBuffers& fb, const SceneView
 void launch_resolve(const FrameBuffers& fb, const LightsParam& lights, const uint32_t* count, hipStream_t s);
 void launch_convert(const FrameParams& fp, const FrameBuffers& fb, const float4* sum_or_null, uint8_t* bgr, hipStream_t s);
 void launch_spp_accumulate(const FrameParams& fp, const FrameBuffers& fb, float4* sum, hipStream_t s);
+struct AnimParam { float m[16]; };          /* column-major rotation of main.cu:548 */
+void animation_matrix(float out16[16]);     /* scene.cpp */
+void launch_animate(crt_prim* d_prims, uint32_t n, const AnimParam& a, hipStream_t s);
 void launch_pack_prims(const crt_prim* d_prims, const uint32_t* d_matid, const uint32_t* slot_of, uint32_t n,
                        Geom* geom, Shade* shade, hipStream_t s);
 void launch_refit(Node4* nodes, uint32_t nnodes, const Geom* geom, uint32_t* arrive, float* root_box, int grow_only,

@@ -1189,6 +1189,44 @@ void launch_pack_prims(const crt_prim* d_prims, const uint32_t* d_matid, const u
 }
 
 /* ------------------------------------------------------------------------------------------
+ * animation step (main.cu:545-573) on the device copy of the scene: triangles (positions and
+ * normals) times the per-frame rotation -- mat4 * vec4(v, 1) evaluated as (m0*x + m1*y) +
+ * (m2*z + m3*1), glm/detail/type_mat4x4.inl:640-651 -- spheres bounce off the room walls and move.
+ * Same expressions, same order, no contraction: bit-identical to crt_animate_host.
+ * ------------------------------------------------------------------------------------------ */
+CRT_DEV void anim_apply(const AnimParam& A, float* v) {
+    float o[3];
+    for (int k = 0; k < 3; k++) {
+        const float a0 = A.m[0 * 4 + k] * v[0] + A.m[1 * 4 + k] * v[1];
+        const float a1 = A.m[2 * 4 + k] * v[2] + A.m[3 * 4 + k] * 1.0f;
+        o[k] = a0 + a1;
+    }
+    v[0] = o[0]; v[1] = o[1]; v[2] = o[2];
+}
+__global__ __launch_bounds__(256) void k_animate(crt_prim* prims, uint32_t n, AnimParam A) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    crt_prim& s = prims[i];
+    if (s.type == 1) {
+        anim_apply(A, s.v1); anim_apply(A, s.v2); anim_apply(A, s.v3);
+        anim_apply(A, s.v1Norm); anim_apply(A, s.v2Norm); anim_apply(A, s.v3Norm);
+    } else if (s.type == 0) {
+        vec3 d(s.direction);
+        if (s.position[0] + s.radius > 200.0f) d = reflect(d, vec3(-1, 0, 0));
+        if (s.position[0] - s.radius < -200.0f) d = reflect(d, vec3(1, 0, 0));
+        if (s.position[1] + s.radius > 200.0f) d = reflect(d, vec3(0, -1, 0));
+        if (s.position[1] - s.radius < -200.0f) d = reflect(d, vec3(0, 1, 0));
+        if (s.position[2] + s.radius > 300.0f) d = reflect(d, vec3(0, 0, -1));
+        if (s.position[2] - s.radius < -300.0f) d = reflect(d, vec3(0, 0, 1));
+        d.store(s.direction);
+        (vec3(s.position) + d * s.speed * 8.0f).store(s.position);
+    }
+}
+void launch_animate(crt_prim* d_prims, uint32_t n, const AnimParam& a, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_animate, dim3((n + 255u) / 256u), dim3(256), 0, s, d_prims, n, a);
+}
+
+/* ------------------------------------------------------------------------------------------
  * refit (refitTree, bvh.cu:288-400): pass 1 recomputes every leaf child's box from its
  * primitives; pass 2 climbs from the nodes that have no internal children, the last child to
  * arrive at a parent (agent-scope arrival counter) carries on.  grow_only keeps the reference's

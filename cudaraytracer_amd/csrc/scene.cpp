@@ -204,6 +204,16 @@ void apply(const Rot& r, float* v) {
 }
 }  // namespace
 
+}  // extern "C"
+namespace crt {
+/* the per-frame rotation of main.cu:548 as 16 floats, column-major, for the device animation kernel */
+void animation_matrix(float out16[16]) {
+    const Rot rot = make_rot(0.01f, vec3(0.0f, 1.0f, 0.0f));
+    for (int c = 0; c < 4; c++) for (int k = 0; k < 4; k++) out16[c * 4 + k] = rot.m[c][k];
+}
+}  // namespace crt
+extern "C" {
+
 int crt_animate_host(crt_prim* prims, int n) {
     if (!prims || n < 0) return CRT_ERR_ARG;
     const Rot rot = make_rot(0.01f, vec3(0.0f, 1.0f, 0.0f));

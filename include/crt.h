@@ -105,6 +105,12 @@ int crt_set_counting(crt_ctx*, int on);   /* per-ray test counters for the algor
 int crt_scene_set(crt_ctx*, const crt_prim* prims, int n);
 int crt_scene_update(crt_ctx*, const crt_prim* prims, int n);   /* moved geometry; same count and order */
 int crt_lights_set(crt_ctx*, const crt_light* lights, int n);
+/* the animation step of main.cu:545-573 (rotate triangles 0.01 rad about Y, bounce and move spheres)
+ * applied to the device copy of the scene and its packed geometry: bit-identical to crt_animate_host +
+ * crt_scene_update without the host loop and the re-upload.  Follow with crt_bvh_refit (or crt_bvh_build,
+ * which first copies the moved scene back for the host builders). */
+int crt_animate_device(crt_ctx*);
+int crt_scene_get(crt_ctx*, crt_prim* prims_out, int n);        /* current scene state (after device animation) */
 
 /* ---- BVH: replaces newBuild+constructTree (main.cu:33-136, bvh.cu:12-273), refitTree
  *      (bvh.cu:288-400) and freeTree (bvh.cu:274-286) ---- */

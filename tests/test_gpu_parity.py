@@ -196,6 +196,35 @@ def test_spheres_scene_and_refit(crt):
         ctx.close(); sc.close()
 
 
+def test_device_animation_equals_host(crt):
+    """A13 on the device: crt_animate_device advances the resident scene exactly as
+    crt_animate_host (itself checked against the oracle above) and the rendered frames agree with the oracle."""
+    prims = np.concatenate([crt.scene_teapot(with_sphere=True), crt.scene_spheres(300, seed=4)])
+    lights = crt.default_lights()
+    cam, tgt = crt.default_camera()
+    ctx = crt.Context(0)
+    ctx.set_scene(prims); ctx.set_lights(lights); ctx.build(0)
+    sc = orc.Scene(prims); sc.build()
+    host = prims.copy()
+    p = crt.default_params(width=320, height=180, bounces=2)
+    try:
+        for frame in range(1, 45):
+            ctx.animate_device()
+            crt.animate_host(host)
+            sc.animate()
+            if frame % 20 == 0:
+                ctx.build(0); sc.build()              # rebuild from the device-animated scene
+            else:
+                ctx.refit(False); sc.refit()
+            if frame in (1, 19, 20, 44):
+                assert ctx.get_scene().tobytes() == host.tobytes(), f"frame {frame}: device animation differs from the host step"
+                g = ctx.render(cam, tgt, p)
+                o = sc.render(lights, cam, tgt, 320, 180, 2, nthreads=16)
+                check_image(g, o, f"device-animated frame {frame}", max_bad=4)
+    finally:
+        ctx.close(); sc.close()
+
+
 def match_reference_tree(dump, root, boxes, links):
     """Walk the oracle's pointer tree and the packed reference-topology nodes together; yield
     (oracle node index, packed box)."""
