@@ -34,13 +34,13 @@ constexpr int kFetchStride = 64;       /* uint32 words between the 8 per-region 
 constexpr int kTraceBlock = 256;       /* 4 waves of 64 */
 constexpr int kStackDepth = CRT_STACK_DEPTH;        /* per-lane entries in LDS: stack[depth][lane], conflict-free per wave */
 #ifndef CRT_REFILL8_MIN_IDLE
-#define CRT_REFILL8_MIN_IDLE 12        /* k_trace8: a refill stalls the wave for a load round trip and runs the ray set-up for the idle lanes only */
+#define CRT_REFILL8_MIN_IDLE 8         /* k_trace8: idle lanes that trigger a refill (its loads complete under the next traversal step) */
 #endif
 #ifndef CRT_TRACE8_MIN_WAVES
-#define CRT_TRACE8_MIN_WAVES 4         /* __launch_bounds__(256, n): waves per SIMD the register allocation must allow (LDS allows 4) */
+#define CRT_TRACE8_MIN_WAVES 5         /* __launch_bounds__(256, n): 96 VGPRs, 5 waves per SIMD; 5 x 30.7 KB of LDS per CU */
 #endif
 #ifndef CRT_STACK_DEPTH8
-#define CRT_STACK_DEPTH8 16
+#define CRT_STACK_DEPTH8 14
 #endif
 constexpr int kRefillMinIdle8 = CRT_REFILL8_MIN_IDLE;
 constexpr int kStackDepth8 = CRT_STACK_DEPTH8;      /* k_trace8: 64-bit entries, at most one per tree level */

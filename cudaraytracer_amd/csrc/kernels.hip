@@ -447,7 +447,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
     int best = -1;
     uint32_t ray = 0;
     uint32_t gbase = 0, gmask = 0;                 /* internal-child group: base node | imask << 8 | permuted hits */
-    uint32_t pbase = 0, meta0 = 0, meta1 = 0, lmask = 0;    /* leaf children hit at the last node, by slot */
+    uint32_t plm = 0, meta0 = 0, meta1 = 0;    /* leaf children hit at the last node: first leaf slot (< 2^24) | hit mask by child << 24 */
     uint32_t lp = 0, lend = 0;
     int sp = 0;
     int found = 0;
@@ -456,6 +456,11 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
     unsigned long long sch[5] = {0, 0, 0, 0, 0};
 
     for (;;) {
+        /* ---- refill, first half: when enough lanes are idle, take rays off the queue and ISSUE their
+         *      loads; the set-up runs after this iteration's traversal step, whose own node / primitive
+         *      loads return later (loads return in order), so the refill costs the wave no extra stall ---- */
+        bool pend = false;
+        float3 pro3; float4 pro4, prd;      /* read only by the lanes that set pend; `ray` carries the queue index */
         if (!exhausted) {
             const unsigned long long idle = __ballot(!active);
             const int nidle = __popcll(idle);
@@ -484,44 +489,16 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
                     const uint32_t take = (uint32_t)nidle < cend - cnext ? (uint32_t)nidle : cend - cnext;
                     const bool mine = !active && idx < cend;
                     cnext += take;
-                    if (mine) {
-                        const float4 ro = A.rayO[idx], rd = A.rayD[idx];
-                        if (MODE == TRACE_NEAREST && __float_as_uint(rd.w) == 0xffffffffu) {
-                            A.hitSlot[idx] = -3;
-                            A.hitT[idx] = 0.f;
-                        } else {
-                            ray = idx;
-                            o = vec3(ro.x, ro.y, ro.z); d = vec3(rd.x, rd.y, rd.z);
-                            if (MODE == TRACE_SHADOW) { ray = __float_as_uint(ro.w); lightj = (int)__float_as_uint(rd.w); }
-                            /* v_rcp_f32 (1 ulp) instead of an IEEE division: the box test only has to be
-                             * conservative and the pad below is 1e4 times that error */
-                            float rx = __builtin_amdgcn_rcpf(d.x), ry = __builtin_amdgcn_rcpf(d.y), rz = __builtin_amdgcn_rcpf(d.z);
-                            if (!(fabsf(d.x) > 1e-20f)) rx = copysignf(1e20f, d.x);
-                            if (!(fabsf(d.y) > 1e-20f)) ry = copysignf(1e20f, d.y);
-                            if (!(fabsf(d.z) > 1e-20f)) rz = copysignf(1e20f, d.z);
-                            ix = rx; iy = ry; iz = rz;
-                            /* boxes are conservative already; the pad covers the rounding of the plane arithmetic */
-                            const float px = 1e-3f + 1e-6f * (fabsf(o.x) + A.scene_abs);
-                            const float py = 1e-3f + 1e-6f * (fabsf(o.y) + A.scene_abs);
-                            const float pz = 1e-3f + 1e-6f * (fabsf(o.z) + A.scene_abs);
-                            const bool ngx = ix < 0.f, ngy = iy < 0.f, ngz = iz < 0.f;
-                            /* near plane: lo row shifted by -pad for a positive direction, hi row by +pad for a negative one */
-                            anx = (ngx ? o.x - px : o.x + px) * ix; afx = (ngx ? o.x + px : o.x - px) * ix;
-                            any_ = (ngy ? o.y - py : o.y + py) * iy; afy = (ngy ? o.y + py : o.y - py) * iy;
-                            anz = (ngz ? o.z - pz : o.z + pz) * iz; afz = (ngz ? o.z + pz : o.z - pz) * iz;
-                            R = (ngx ? 0u : 4u) | (ngy ? 0u : 2u) | (ngz ? 0u : 1u);
-                            tbest = 1000000000.0f; best = -1; sp = 0; found = 0; lp = lend = 0; lmask = 0;
-                            gbase = 0; gmask = (1u << 8) | (1u << R);      /* a group whose only child is the root */
-                            active = true;
-                        }
+                    if (mine) {          /* issue the loads only: they complete under the traversal step below */
+                        if (MODE == TRACE_SHADOW) pro4 = A.rayO[idx];
+                        else pro3 = *reinterpret_cast<const float3*>(A.rayO + idx);      /* .w is only used by shadow rays */
+                        prd = A.rayD[idx]; ray = idx; pend = true;
                     }
                 }
             }
         }
-        if (__ballot(active) == 0ull) { if (exhausted) break; else continue; }
-
-        do {
-            const bool want_prim = active && (lp < lend || lmask != 0u);
+        if (__ballot(active) != 0ull) {
+            const bool want_prim = active && (lp < lend || plm >= (1u << 24));
             const bool want_node = active && !want_prim;
             const int n_node = __popcll(__ballot(want_node));
             const int n_prim = __popcll(__ballot(want_prim));
@@ -596,18 +573,18 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
                         if (COUNT) { nbox += (unsigned long long)__popc(vmask); nvis++; }
                         gbase = h1.x & 0xffffffu;
                         gmask = (imask << 8) | (uint32_t)s_perm[R][raw & imask];
-                        lmask = raw & ~imask;
-                        pbase = h1.y; meta0 = h1.z; meta1 = h1.w;
+                        plm = h1.y | ((raw & ~imask) << 24);
+                        meta0 = h1.z; meta1 = h1.w;
                         if (raw == 0u && sp == 0) finish = true;
                     }
                 }
             } else {
                 if (want_prim) {
                     if (lp == lend) {
-                        const uint32_t k = (uint32_t)__ffs((int)lmask) - 1u;
-                        lmask &= lmask - 1u;
+                        const uint32_t k = (uint32_t)__ffs((int)(plm >> 24)) - 1u;
+                        plm &= ~(1u << (24u + k));
                         const uint32_t m = ((k & 4u) ? meta1 : meta0) >> ((k & 3u) * 8u);
-                        lp = pbase + (m & 31u);
+                        lp = (plm & 0xffffffu) + (m & 31u);
                         lend = lp + ((m >> 5) & 3u) + 1u;
                     }
                     const uint32_t p = lp++;
@@ -628,7 +605,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
                             }
                         }
                     }
-                    if (lp == lend && lmask == 0u && (gmask & 0xffu) == 0u && sp == 0) finish = true;
+                    if (lp == lend && plm < (1u << 24) && (gmask & 0xffu) == 0u && sp == 0) finish = true;
                 }
             }
             if (finish) {
@@ -651,9 +628,43 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
                     } else shadowed = (found != 0);
                     if (shadowed) A.shflag[ray] = 1;
                 }
-                active = false; lp = lend = 0; lmask = 0;
+                active = false; lp = lend = 0; plm = 0;
             }
-        } while (exhausted ? (__ballot(active) != 0ull) : (__popcll(__ballot(active)) > 64 - kRefillMinIdle8));
+        }
+        /* ---- refill, second half: ray set-up for the lanes whose loads were issued above ---- */
+        if (pend) {
+            const float4 ro = MODE == TRACE_SHADOW ? pro4 : make_float4(pro3.x, pro3.y, pro3.z, 0.f), rd = prd;
+            const uint32_t idx = ray;
+            if (MODE == TRACE_NEAREST && __float_as_uint(rd.w) == 0xffffffffu) {
+                A.hitSlot[idx] = -3;
+                A.hitT[idx] = 0.f;
+            } else {
+                ray = idx;
+                o = vec3(ro.x, ro.y, ro.z); d = vec3(rd.x, rd.y, rd.z);
+                if (MODE == TRACE_SHADOW) { ray = __float_as_uint(ro.w); lightj = (int)__float_as_uint(rd.w); }
+                /* v_rcp_f32 (1 ulp) instead of an IEEE division: the box test only has to be
+                 * conservative and the pad below is 1e4 times that error */
+                float rx = __builtin_amdgcn_rcpf(d.x), ry = __builtin_amdgcn_rcpf(d.y), rz = __builtin_amdgcn_rcpf(d.z);
+                if (!(fabsf(d.x) > 1e-20f)) rx = copysignf(1e20f, d.x);
+                if (!(fabsf(d.y) > 1e-20f)) ry = copysignf(1e20f, d.y);
+                if (!(fabsf(d.z) > 1e-20f)) rz = copysignf(1e20f, d.z);
+                ix = rx; iy = ry; iz = rz;
+                /* boxes are conservative already; the pad covers the rounding of the plane arithmetic */
+                const float px = 1e-3f + 1e-6f * (fabsf(o.x) + A.scene_abs);
+                const float py = 1e-3f + 1e-6f * (fabsf(o.y) + A.scene_abs);
+                const float pz = 1e-3f + 1e-6f * (fabsf(o.z) + A.scene_abs);
+                const bool ngx = ix < 0.f, ngy = iy < 0.f, ngz = iz < 0.f;
+                /* near plane: lo row shifted by -pad for a positive direction, hi row by +pad for a negative one */
+                anx = (ngx ? o.x - px : o.x + px) * ix; afx = (ngx ? o.x + px : o.x - px) * ix;
+                any_ = (ngy ? o.y - py : o.y + py) * iy; afy = (ngy ? o.y + py : o.y - py) * iy;
+                anz = (ngz ? o.z - pz : o.z + pz) * iz; afz = (ngz ? o.z + pz : o.z - pz) * iz;
+                R = (ngx ? 0u : 4u) | (ngy ? 0u : 2u) | (ngz ? 0u : 1u);
+                tbest = 1000000000.0f; best = -1; sp = 0; found = 0; lp = lend = 0; plm = 0;
+                gbase = 0; gmask = (1u << 8) | (1u << R);      /* a group whose only child is the root */
+                active = true;
+            }
+        }
+        if (exhausted && __ballot(active) == 0ull) break;
     }
     if (COUNT) {
         atomicAdd(&A.counters[0], nbox);
@@ -732,7 +743,7 @@ __global__ __launch_bounds__(256) void k_quantize8(const Node8* nodes, uint32_t 
             nint++;
         }
     }
-    if (bad || cbase >= (1u << 24)) atomicOr(status, 2u);
+    if (bad || cbase >= (1u << 24) || pb >= (1u << 24)) atomicOr(status, 2u);     /* both bases share a word with an 8-bit mask */
     float org[3];
     uint32_t ex[3];
     for (int a = 0; a < 3; a++) {
