@@ -67,6 +67,7 @@ struct crt_ctx {
     uint8_t* d_bgr = nullptr; size_t bgr_cap = 0;
     int32_t* cap_ids = nullptr; float* cap_ts = nullptr; size_t cap_planes = 0; size_t cap_npix = 0;
     uint32_t* d_tiles = nullptr; size_t tiles_cap = 0; std::vector<uint32_t> tiles; crt_params tiles_for{}; int64_t owned_pixels = 0;
+    std::vector<uint32_t*> tl_ids; std::vector<int> tl_n; crt_params tl_key{};      /* per-rank tile lists for pack/unpack */
     uint32_t* d_ctr = nullptr; size_t ctr_cap = 0; std::vector<uint32_t> h_ctr;
     uint32_t* d_status = nullptr;
     unsigned long long* d_testctr = nullptr;
@@ -328,6 +329,7 @@ void crt_destroy(crt_ctx* c) {
                     c->accum, c->sum, c->shflag, c->d_bgr, c->cap_ids, c->cap_ts, c->d_tiles, c->d_ctr, c->d_status,
                     c->d_testctr, c->d_ovf};
     for (void* p : ptrs) if (p) hipFree(p);
+    for (uint32_t* q : c->tl_ids) if (q) hipFree(q);
     for (hipEvent_t e : c->evpool) hipEventDestroy(e);
     hipStreamDestroy(c->stream);
     delete c;
@@ -864,27 +866,45 @@ int crt_blob_import_device(crt_ctx* c, const void* dev_ptr, size_t bytes) {
     return size_overflow(c);
 }
 
+/* tile lists of every rank for the gather, resident on the device and cached per frame geometry */
+static int tile_list(crt_ctx* c, const crt_params* p, int rank, uint32_t** d_ids, int* ntiles) {
+    crt_params key = *p; key.rank = 0; key.bounces = 0; key.spp = 0; key.sort_rays = 0;
+    if (c->tl_ids.empty() || memcmp(&key, &c->tl_key, sizeof key) != 0) {
+        HIPCHECK(c, hipStreamSynchronize(c->stream));
+        for (uint32_t* q : c->tl_ids) if (q) hipFree(q);
+        c->tl_ids.assign((size_t)p->nranks, nullptr); c->tl_n.assign((size_t)p->nranks, 0);
+        c->tl_key = key;
+    }
+    if (!c->tl_ids[rank]) {
+        crt_params q = *p; q.rank = rank;
+        int nt = 0; int64_t np = 0;
+        int rc = crt_tiles_owned(&q, &nt, &np, nullptr, 0);
+        if (rc) return fail(c, rc, "tiles pack/unpack: bad params");
+        std::vector<int32_t> ids(nt);
+        crt_tiles_owned(&q, &nt, &np, ids.data(), nt);
+        HIPCHECK(c, hipMalloc((void**)&c->tl_ids[rank], (size_t)(nt + 1) * 4));
+        HIPCHECK(c, hipMemcpy(c->tl_ids[rank], ids.data(), (size_t)nt * 4, hipMemcpyHostToDevice));
+        c->tl_n[rank] = nt;
+    }
+    *d_ids = c->tl_ids[rank]; *ntiles = c->tl_n[rank];
+    return CRT_OK;
+}
+
 static int tiles_copy(crt_ctx* c, const crt_params* p, int src_rank, const void* src, void* dst, int to_packed) {
     if (!c || !p || !src || !dst) return fail(c, CRT_ERR_ARG, "tiles pack/unpack: null argument");
+    if (p->nranks < 1 || src_rank < 0 || src_rank >= p->nranks) return fail(c, CRT_ERR_ARG, "tiles pack/unpack: bad rank");
     HIPCHECK(c, hipSetDevice(c->device));
-    crt_params q = *p; q.rank = src_rank;
-    int nt = 0; int64_t np = 0;
-    int rc = crt_tiles_owned(&q, &nt, &np, nullptr, 0);
-    if (rc) return fail(c, rc, "tiles pack/unpack: bad params");
-    std::vector<int32_t> ids(nt);
-    crt_tiles_owned(&q, &nt, &np, ids.data(), nt);
-    uint32_t* d_ids = nullptr;
-    HIPCHECK(c, hipMalloc((void**)&d_ids, (size_t)(nt + 1) * 4));
-    hipError_t e = hipMemcpyAsync(d_ids, ids.data(), (size_t)nt * 4, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) {
-        FrameParams fp{};
-        fp.width = p->width; fp.height = p->height; fp.tile_w = p->tile_w; fp.tile_h = p->tile_h;
-        fp.tiles_x = (p->width + p->tile_w - 1) / p->tile_w; fp.ntiles_owned = nt;
-        launch_tiles_copy(fp, d_ids, nt, (const uint8_t*)src, (uint8_t*)dst, to_packed, c->stream);
-        e = hipStreamSynchronize(c->stream);
-    }
-    hipFree(d_ids);
-    if (e != hipSuccess) { c->err = std::string("tiles copy: ") + hipGetErrorString(e); return CRT_ERR_HIP; }
+    uint32_t* d_ids = nullptr; int nt = 0;
+    int rc = tile_list(c, p, src_rank, &d_ids, &nt);
+    if (rc) return rc;
+    FrameParams fp{};
+    fp.width = p->width; fp.height = p->height; fp.tile_w = p->tile_w; fp.tile_h = p->tile_h;
+    fp.tiles_x = (p->width + p->tile_w - 1) / p->tile_w; fp.ntiles_owned = nt;
+    launch_tiles_copy(fp, d_ids, nt, (const uint8_t*)src, (uint8_t*)dst, to_packed, c->stream);
+    HIPCHECK(c, hipGetLastError());
+    /* packing is followed by a collective on another stream: finish it here.  Unpacks of several
+     * ranks queue up on the context's stream; crt_sync() (or the next render) completes them. */
+    if (to_packed) HIPCHECK(c, hipStreamSynchronize(c->stream));
     return CRT_OK;
 }
 int crt_tiles_pack(crt_ctx* c, const crt_params* p, const void* dev_bgr, void* dev_packed) {

@@ -145,5 +145,6 @@ class ShardedRenderer:
             self.torch.cuda.synchronize(self.dev)
             for r in range(1, self.world):
                 self.ctx.tiles_unpack(params, r, self.gathered[r].data_ptr(), self.frame.data_ptr())
+            self.ctx.sync()
             return self.frame
         return None

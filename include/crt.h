@@ -157,7 +157,8 @@ int crt_blob_import_device(crt_ctx*, const void* dev_ptr, size_t bytes);   /* co
 int crt_tile_owner(int tile_index, int nranks);
 /* number of tiles this rank owns and their pixel count; tile list in owned order */
 int crt_tiles_owned(const crt_params*, int32_t* ntiles, int64_t* npixels, int32_t* tile_ids, int cap);
-/* pack this rank's tiles of dev_bgr tile-major into dev_packed (npixels*3 bytes) and back */
+/* pack this rank's tiles of dev_bgr tile-major into dev_packed (npixels*3 bytes) and back.  Pack returns
+ * with the copy finished (a collective follows); unpacks queue on the context's stream: crt_sync() ends them. */
 int crt_tiles_pack(crt_ctx*, const crt_params*, const void* dev_bgr, void* dev_packed);
 int crt_tiles_unpack(crt_ctx*, const crt_params*, int src_rank, const void* dev_packed, void* dev_bgr);
 

@@ -71,6 +71,7 @@ def test_logical_ranks_rebuild_the_frame(world, w, h):
                 own = hip.to_host(frame, w * h * 3).reshape(h, w, 3)
                 assert np.array_equal(hip.to_host(packed, nb), parallel.pack_tiles_host(p, r, own))
                 root.tiles_unpack(p, r, packed, frame0)
+        root.sync()                                         # unpacks queue on the root context's stream
         got = hip.to_host(frame0, w * h * 3).reshape(h, w, 3)
         assert np.array_equal(got, full)
         # rays issued by the ranks add up to the single-rank count
