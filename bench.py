@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--bounces", type=int, default=3)
     ap.add_argument("--spp", type=int, default=1)
     ap.add_argument("--bvh", type=int, default=0, help="0 wide SAH (default), 1 reference topology")
+    ap.add_argument("--sort-rays", type=int, default=0, help="1: visit secondary rays in Morton order of their origin cell")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--out-bmp", default=None)
@@ -106,7 +107,8 @@ def main():
 
     cam, tgt = crt.default_camera()
     lights = crt.default_lights()
-    params = crt.default_params(width=a.width, height=a.height, bounces=a.bounces, spp=a.spp, rank=rank, nranks=world)
+    params = crt.default_params(width=a.width, height=a.height, bounces=a.bounces, spp=a.spp, rank=rank, nranks=world,
+                                sort_rays=a.sort_rays)
     prims = crt.scene_soup(a.tris, seed=1) if (rank == 0 or world == 1) else None
     log(f"scene generated: {a.tris} triangles")
 
@@ -214,7 +216,7 @@ def main():
             "config": {
                 "workload": f"configs[3]: synthetic {a.tris}-triangle random soup (seed 1), {a.width}x{a.height}, "
                             f"bounces={a.bounces} (primary + {a.bounces - 1} reflections), 2 directional lights, "
-                            f"spp={a.spp}; frame tiles 32x32 sharded over {world} GPU(s)",
+                            f"spp={a.spp}; frame tiles 32x32 sharded over {world} GPU(s)" + ("; sorted secondary rays" if a.sort_rays else ""),
                 "bvh": "wide8-sah-compressed" if a.bvh == 0 else "reference-topology",
                 "rays_per_frame": {"primary": int(rays[0]), "shadow": int(rays[1]), "reflect": int(rays[2])},
                 "frame_ms_device_rank0": round(acc["ms_total"] / a.steps, 4),

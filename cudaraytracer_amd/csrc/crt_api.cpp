@@ -69,6 +69,7 @@ struct crt_ctx {
     uint32_t* d_tiles = nullptr; size_t tiles_cap = 0; std::vector<uint32_t> tiles; crt_params tiles_for{}; int64_t owned_pixels = 0;
     std::vector<uint32_t*> tl_ids; std::vector<int> tl_n; crt_params tl_key{};      /* per-rank tile lists for pack/unpack */
     uint32_t* d_ctr = nullptr; size_t ctr_cap = 0; std::vector<uint32_t> h_ctr;
+    uint32_t *d_sortkeys = nullptr, *d_sortperm = nullptr, *d_sorthist = nullptr; size_t sort_cap = 0;
     uint32_t* d_status = nullptr;
     unsigned long long* d_testctr = nullptr;
     uint32_t* d_ovf = nullptr; size_t ovf_cap = 0; int ovf_depth = 0;
@@ -200,7 +201,7 @@ hipEvent_t next_event(crt_ctx* c) {
     if (c->evused == c->evpool.size()) { hipEvent_t e; hipEventCreate(&e); c->evpool.push_back(e); }
     return c->evpool[c->evused++];
 }
-enum { EV_START = 0, EV_GEN, EV_TRACE_N, EV_SHADE, EV_TRACE_S, EV_RESOLVE, EV_CONVERT };
+enum { EV_START = 0, EV_GEN, EV_TRACE_N, EV_SHADE, EV_TRACE_S, EV_RESOLVE, EV_CONVERT, EV_SORT };
 void mark(crt_ctx* c, int kind) {
     hipEvent_t e = next_event(c);
     hipEventRecord(e, c->stream);
@@ -327,7 +328,7 @@ void crt_destroy(crt_ctx* c) {
     void* ptrs[] = {c->d_blob, c->d_prims, c->d_matid, c->d_arrive, c->rayO[0], c->rayO[1], c->rayD[0], c->rayD[1],
                     c->coef[0], c->coef[1], c->pix[0], c->pix[1], c->hitSlot, c->hitT, c->rc, c->contrib, c->shO, c->shD,
                     c->accum, c->sum, c->shflag, c->d_bgr, c->cap_ids, c->cap_ts, c->d_tiles, c->d_ctr, c->d_status,
-                    c->d_testctr, c->d_ovf};
+                    c->d_testctr, c->d_ovf, c->d_sortkeys, c->d_sortperm, c->d_sorthist};
     for (void* p : ptrs) if (p) hipFree(p);
     for (uint32_t* q : c->tl_ids) if (q) hipFree(q);
     for (hipEvent_t e : c->evpool) hipEventDestroy(e);
@@ -632,6 +633,15 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
         if (rc) return rc;
         dev_bgr = c->d_bgr;
     }
+    if (p->sort_rays) {
+        const size_t need = c->cap * (size_t)(c->lights.n > 1 ? c->lights.n : 1);
+        if (need > c->sort_cap || !c->d_sortkeys) {
+            if ((rc = realloc_exact(c, c->d_sortkeys, need))) return rc;
+            if ((rc = realloc_exact(c, c->d_sortperm, need))) return rc;
+            if (!c->d_sorthist && (rc = realloc_exact(c, c->d_sorthist, (size_t)kSortBins + 1))) return rc;
+            c->sort_cap = need;
+        }
+    }
     rc = ensure(c, c->d_ctr, c->ctr_cap, (size_t)spp * kCtrStride);
     if (rc) return rc;
     c->h_ctr.assign((size_t)spp * kCtrStride, 0);
@@ -665,6 +675,13 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
             TraceArgs ta{};
             ta.sv = sv; ta.rayO = fb.rayO; ta.rayD = fb.rayD; ta.count = ctr + b; ta.next = ctr + kCtrFetch0 + (2 * b) * 8 * kFetchStride;
             ta.hitSlot = c->hitSlot; ta.hitT = c->hitT; ta.shflag = nullptr; ta.scene_abs = c->scene_abs;
+            const float* d_root_box = (const float*)((const char*)c->d_blob + offsetof(BlobHeader, root_box));
+            const bool wide = c->hdr.mode == CRT_BVH_WIDE;
+            if (p->sort_rays && wide && b > 0) {        /* reflection rays: visit them by origin cell (primary rays are coherent already) */
+                launch_sort_rays(fb.rayO, ctr + b, (uint32_t)c->cap, d_root_box, c->d_sortkeys, c->d_sorthist, c->d_sortperm, c->stream);
+                ta.perm = c->d_sortperm;
+                mark(c, EV_SORT);
+            }
             ta.ovf = c->d_ovf; ta.ovf_depth = c->ovf_depth; ta.counters = c->d_testctr; ta.status = c->d_status;
             launch_trace(ta, c->lights, TRACE_NEAREST, c->counting, c->hdr.mode == CRT_BVH_WIDE, c->grid_blocks, c->stream);
             mark(c, EV_TRACE_N);
@@ -674,6 +691,13 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
                 TraceArgs ts = ta;
                 ts.rayO = c->shO; ts.rayD = c->shD; ts.count = ctr + 16 + b; ts.next = ctr + kCtrFetch0 + (2 * b + 1) * 8 * kFetchStride;
                 ts.hitSlot = nullptr; ts.hitT = nullptr; ts.shflag = c->shflag; ts.counters = c->d_testctr + 16;
+                ts.perm = nullptr;
+                if (p->sort_rays && wide) {
+                    launch_sort_rays(c->shO, ctr + 16 + b, (uint32_t)(c->cap * (size_t)c->lights.n), d_root_box, c->d_sortkeys, c->d_sorthist,
+                                     c->d_sortperm, c->stream);
+                    ts.perm = c->d_sortperm;
+                    mark(c, EV_SORT);
+                }
                 launch_trace(ts, c->lights, TRACE_SHADOW, c->counting, c->hdr.mode == CRT_BVH_WIDE, c->grid_blocks, c->stream);
                 mark(c, EV_TRACE_S);
             }

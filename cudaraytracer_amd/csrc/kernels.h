@@ -90,6 +90,7 @@ struct TraceArgs {
     SceneView sv;
     const float4* rayO; const float4* rayD;
     const uint32_t* count;       /* number of rays (device) */
+    const uint32_t* perm;        /* optional visiting order (crt_params.sort_rays): queue position -> ray, or null */
     uint32_t* next;              /* 8 fetch counters, kFetchStride words apart (device, zeroed) */
     int32_t* hitSlot; float* hitT;           /* NEAREST outputs */
     uint8_t* shflag;                         /* SHADOW output, indexed by the target in rayO.w */
@@ -108,6 +109,12 @@ void launch_shade(const FrameParams& fp, const FrameBuffers& fb, const SceneView
 void launch_resolve(const FrameBuffers& fb, const LightsParam& lights, const uint32_t* count, hipStream_t s);
 void launch_convert(const FrameParams& fp, const FrameBuffers& fb, const float4* sum_or_null, uint8_t* bgr, hipStream_t s);
 void launch_spp_accumulate(const FrameParams& fp, const FrameBuffers& fb, float4* sum, hipStream_t s);
+/* optional ray sorting (crt_params.sort_rays): visiting order of a ray queue by the Morton code of the
+ * origin's cell in a 32^3 grid over the root box.  keys/perm: one word per ray; hist: kSortBins + 1 words. */
+constexpr int kSortBits = 5;
+constexpr int kSortBins = 1 << (3 * kSortBits);
+void launch_sort_rays(const float4* rayO, const uint32_t* count, uint32_t cap, const float* root_box6, uint32_t* keys,
+                      uint32_t* hist, uint32_t* perm, hipStream_t s);
 struct AnimParam { float m[16]; };          /* column-major rotation of main.cu:548 */
 void animation_matrix(float out16[16]);     /* scene.cpp */
 void launch_animate(crt_prim* d_prims, uint32_t n, const AnimParam& a, hipStream_t s);

@@ -490,9 +490,10 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
                     const bool mine = !active && idx < cend;
                     cnext += take;
                     if (mine) {          /* issue the loads only: they complete under the traversal step below */
-                        if (MODE == TRACE_SHADOW) pro4 = A.rayO[idx];
-                        else pro3 = *reinterpret_cast<const float3*>(A.rayO + idx);      /* .w is only used by shadow rays */
-                        prd = A.rayD[idx]; ray = idx; pend = true;
+                        const uint32_t q = A.perm ? A.perm[idx] : idx;      /* sorted visiting order, if any */
+                        if (MODE == TRACE_SHADOW) pro4 = A.rayO[q];
+                        else pro3 = *reinterpret_cast<const float3*>(A.rayO + q);        /* .w is only used by shadow rays */
+                        prd = A.rayD[q]; ray = q; pend = true;
                     }
                 }
             }
@@ -795,6 +796,90 @@ __global__ __launch_bounds__(256) void k_quantize8(const Node8* nodes, uint32_t 
 }
 void launch_quantize(const Node8* nodes, uint32_t nnodes, QNode8* qnodes, uint32_t* status, hipStream_t s) {
     if (nnodes) hipLaunchKernelGGL(k_quantize8, dim3((nnodes + 255u) / 256u), dim3(256), 0, s, nodes, nnodes, qnodes, status);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * optional ray sorting (the reference's own sketch is the nw/ne/sw/se counters of
+ * Ray.cu:526-541): a counting sort of queue positions by the Morton code of the origin's cell.
+ * Only the visiting order changes (TraceArgs::perm); every ray still writes its result at its own
+ * queue index, so images are identical with and without it.
+ * ------------------------------------------------------------------------------------------ */
+CRT_DEV int lane_id() { return (int)(threadIdx.x & 63u); }
+CRT_DEV uint32_t spread3(uint32_t v) {        /* 5 bits -> every third bit */
+    v = (v | (v << 8)) & 0x0000f00fu;
+    v = (v | (v << 4)) & 0x000c30c3u;
+    v = (v | (v << 2)) & 0x00249249u;
+    return v;
+}
+__global__ __launch_bounds__(256) void k_sort_count(const float4* rayO, const uint32_t* count, const float* box, uint32_t* keys, uint32_t* hist) {
+    const uint32_t total = *count;
+    const float lx = box[0], ly = box[2], lz = box[4];
+    const float sx = (float)(1 << kSortBits) / fmaxf(box[1] - box[0], 1e-20f), sy = (float)(1 << kSortBits) / fmaxf(box[3] - box[2], 1e-20f),
+                sz = (float)(1 << kSortBits) / fmaxf(box[5] - box[4], 1e-20f);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const float4 o = rayO[i];
+        const int m = (1 << kSortBits) - 1;
+        int cx = (int)((o.x - lx) * sx), cy = (int)((o.y - ly) * sy), cz = (int)((o.z - lz) * sz);
+        cx = cx < 0 ? 0 : (cx > m ? m : cx); cy = cy < 0 ? 0 : (cy > m ? m : cy); cz = cz < 0 ? 0 : (cz > m ? m : cz);
+        const uint32_t key = spread3((uint32_t)cx) | (spread3((uint32_t)cy) << 1) | (spread3((uint32_t)cz) << 2);
+        keys[i] = key;
+        /* neighbouring rays mostly share a cell: one atomic per distinct key of the wave, not one per lane
+         * (same-address atomics serialise) */
+        unsigned long long todo = __ballot(1);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t k = (uint32_t)__shfl((int)key, leader);
+            const unsigned long long same = __ballot(key == k);
+            if (lane_id() == leader) atomicAdd(&hist[k], (uint32_t)__popcll(same));
+            todo &= ~same;
+            if (key == k) break;
+        }
+    }
+}
+/* exclusive scan of the kSortBins counters in place: one block, each thread owns a run of bins */
+__global__ __launch_bounds__(1024) void k_sort_scan(uint32_t* hist) {
+    __shared__ uint32_t s_sum[1024];
+    constexpr int per = kSortBins / 1024;
+    uint32_t local[per];
+    uint32_t acc = 0;
+    for (int k = 0; k < per; k++) { local[k] = acc; acc += hist[threadIdx.x * per + k]; }
+    s_sum[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t v = threadIdx.x >= (unsigned)off ? s_sum[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_sum[threadIdx.x] += v;
+        __syncthreads();
+    }
+    const uint32_t base = threadIdx.x ? s_sum[threadIdx.x - 1] : 0u;
+    for (int k = 0; k < per; k++) hist[threadIdx.x * per + k] = base + local[k];
+}
+__global__ __launch_bounds__(256) void k_sort_scatter(const uint32_t* keys, const uint32_t* count, uint32_t* cursor, uint32_t* perm) {
+    const uint32_t total = *count;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint32_t key = keys[i];
+        unsigned long long todo = __ballot(1);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t k = (uint32_t)__shfl((int)key, leader);
+            const unsigned long long same = __ballot(key == k);
+            uint32_t base = 0;
+            if (lane_id() == leader) base = atomicAdd(&cursor[k], (uint32_t)__popcll(same));
+            base = (uint32_t)__shfl((int)base, leader);
+            todo &= ~same;
+            if (key == k) { perm[base + (uint32_t)__popcll(same & ((1ull << lane_id()) - 1ull))] = i; break; }
+        }
+    }
+}
+void launch_sort_rays(const float4* rayO, const uint32_t* count, uint32_t cap, const float* root_box6, uint32_t* keys,
+                      uint32_t* hist, uint32_t* perm, hipStream_t s) {
+    (void)hipMemsetAsync(hist, 0, sizeof(uint32_t) * kSortBins, s);
+    uint32_t blocks = (cap + 255u) / 256u;
+    if (blocks > 8192u) blocks = 8192u;
+    if (blocks < 1u) blocks = 1u;
+    hipLaunchKernelGGL(k_sort_count, dim3(blocks), dim3(256), 0, s, rayO, count, root_box6, keys, hist);
+    hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, s, hist);
+    hipLaunchKernelGGL(k_sort_scatter, dim3(blocks), dim3(256), 0, s, keys, count, hist, perm);
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -70,7 +70,8 @@ typedef struct crt_params {
     int32_t spp;             /* 1; n*n stratified samples when a perfect square > 1 (extension) */
     int32_t tile_w, tile_h;  /* image tile for sharding, default 32 x 32 */
     int32_t rank, nranks;    /* this context renders tiles t with crt_tile_owner(t, nranks) == rank; 0, 1 */
-    int32_t sort_rays;       /* 0/1: bin secondary rays by origin cell + direction octant between bounces */
+    int32_t sort_rays;       /* 0/1: visit reflection and shadow rays in Morton order of their origin's cell (32^3 grid over
+                              * the scene box; wide BVH only).  Changes the visiting order only, never the image. */
     int32_t reserved[7];
 } crt_params;
 

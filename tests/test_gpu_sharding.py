@@ -82,6 +82,29 @@ def test_logical_ranks_rebuild_the_frame(world, w, h):
         hip.free_all()
 
 
+def test_sorted_rays_change_nothing_but_the_order():
+    """crt_params.sort_rays only permutes the order in which the traversal kernel visits
+    the secondary rays: frame and ray counts are identical."""
+    import cudaraytracer_amd as crt
+    prims = np.concatenate([crt.scene_soup(40000, seed=2), crt.scene_spheres(200, seed=2)])
+    lights = np.zeros(3, crt.LIGHT_DTYPE)
+    lights[:2] = crt.default_lights()
+    lights[2]["point"] = 1; lights[2]["position"] = (4, 3, -4); lights[2]["color"] = (.5, .5, .5)
+    lights[2]["constantTerm"] = 0.25; lights[2]["linearTerm"] = 0.003372407; lights[2]["quadraticTerm"] = 0.000045492
+    ctx = crt.Context(0)
+    ctx.set_scene(prims); ctx.set_lights(lights); ctx.build(0)
+    cam, tgt = crt.default_camera()
+    try:
+        a = ctx.render(cam, tgt, crt.default_params(width=500, height=300, bounces=4, sort_rays=0))
+        sa = ctx.stats()
+        b = ctx.render(cam, tgt, crt.default_params(width=500, height=300, bounces=4, sort_rays=1))
+        sb = ctx.stats()
+        assert np.array_equal(a, b)
+        assert all(sa[k] == sb[k] for k in ("rays_primary", "rays_shadow", "rays_reflect"))
+    finally:
+        ctx.close()
+
+
 def test_spp_extension_is_inert_at_1_and_smooth_at_4():
     import cudaraytracer_amd as crt
     prims = crt.scene_teapot()
