@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--bounces", type=int, default=3)
     ap.add_argument("--spp", type=int, default=1)
-    ap.add_argument("--bvh", type=int, default=0, help="0 wide SAH (default), 1 reference topology")
+    ap.add_argument("--bvh", type=int, default=0, help="0 wide SAH built on the host (default), 1 reference topology, 2 wide LBVH built on the device")
     ap.add_argument("--sort-rays", type=int, default=0, help="1: visit secondary rays in Morton order of their origin cell")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
@@ -217,7 +217,7 @@ def main():
                 "workload": f"configs[3]: synthetic {a.tris}-triangle random soup (seed 1), {a.width}x{a.height}, "
                             f"bounces={a.bounces} (primary + {a.bounces - 1} reflections), 2 directional lights, "
                             f"spp={a.spp}; frame tiles 32x32 sharded over {world} GPU(s)" + ("; sorted secondary rays" if a.sort_rays else ""),
-                "bvh": "wide8-sah-compressed" if a.bvh == 0 else "reference-topology",
+                "bvh": {0: "wide8-sah-compressed", 1: "reference-topology", 2: "wide8-lbvh-device-built"}[a.bvh],
                 "rays_per_frame": {"primary": int(rays[0]), "shadow": int(rays[1]), "reflect": int(rays[2])},
                 "frame_ms_device_rank0": round(acc["ms_total"] / a.steps, 4),
                 "frame_ms_split_rank0": {"trace_nearest": round(acc["ms_trace_nearest"] / a.steps, 4),
@@ -225,10 +225,10 @@ def main():
                                          "shade_resolve": round(acc["ms_shade"] / a.steps, 4),
                                          "gen_convert": round(acc["ms_other"] / a.steps, 4)},
                 "bvh_nodes": cst["nodes"], "bvh_depth": cst["depth"], "scene_bytes": cst["scene_bytes"],
-                "bvh_build_host_ms": round(cst["ms_build_host"], 1),
+                "bvh_build_host_ms": round(cst["ms_build_host"], 1), "bvh_build_device_ms": round(cst["ms_build_device"], 2),
             },
             "roofline": {
-                "kernel": "k_trace8<NEAREST>" if a.bvh == 0 else "k_trace<NEAREST>", "bound": "hbm",
+                "kernel": "k_trace8<NEAREST>" if a.bvh != 1 else "k_trace<NEAREST>", "bound": "hbm",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
@@ -238,7 +238,7 @@ def main():
                             "box_tests": round(cst["box_tests"] / max(1, n_near), 2),
                             "tri_tests": round(cst["tri_tests"] / max(1, n_near), 2),
                             "bytes": round(bytes_near / max(1, n_near), 1)},
-                "shadow_kernel": {"kernel": "k_trace8<SHADOW>" if a.bvh == 0 else "k_trace<SHADOW>", "achieved": round(sh_achieved, 2),
+                "shadow_kernel": {"kernel": "k_trace8<SHADOW>" if a.bvh != 1 else "k_trace<SHADOW>", "achieved": round(sh_achieved, 2),
                                   "frac": round(sh_achieved / HBM_PEAK_GBS, 5), "avg_launch_ms": round(sh_avg_ms, 4),
                                   "per_ray_node_visits": round(cst["node_visits_shadow"] / max(1, cst["rays_shadow"]), 2),
                                   "per_ray_box_tests": round(cst["box_tests_shadow"] / max(1, cst["rays_shadow"]), 2),

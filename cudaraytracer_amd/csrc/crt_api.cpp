@@ -70,6 +70,9 @@ struct crt_ctx {
     std::vector<uint32_t*> tl_ids; std::vector<int> tl_n; crt_params tl_key{};      /* per-rank tile lists for pack/unpack */
     uint32_t* d_ctr = nullptr; size_t ctr_cap = 0; std::vector<uint32_t> h_ctr;
     uint32_t *d_sortkeys = nullptr, *d_sortperm = nullptr, *d_sorthist = nullptr; size_t sort_cap = 0;
+    void* d_lbvh = nullptr; size_t lbvh_cap = 0;                 /* scratch of the device builder */
+    Node8* d_lbvh_nodes = nullptr; size_t lbvh_nodes_cap = 0;    /* its output before the blob is laid out */
+    uint32_t* d_lbvh_s2s = nullptr; size_t lbvh_s2s_cap = 0;
     uint32_t* d_status = nullptr;
     unsigned long long* d_testctr = nullptr;
     uint32_t* d_ovf = nullptr; size_t ovf_cap = 0; int ovf_depth = 0;
@@ -328,7 +331,8 @@ void crt_destroy(crt_ctx* c) {
     void* ptrs[] = {c->d_blob, c->d_prims, c->d_matid, c->d_arrive, c->rayO[0], c->rayO[1], c->rayD[0], c->rayD[1],
                     c->coef[0], c->coef[1], c->pix[0], c->pix[1], c->hitSlot, c->hitT, c->rc, c->contrib, c->shO, c->shD,
                     c->accum, c->sum, c->shflag, c->d_bgr, c->cap_ids, c->cap_ts, c->d_tiles, c->d_ctr, c->d_status,
-                    c->d_testctr, c->d_ovf, c->d_sortkeys, c->d_sortperm, c->d_sorthist};
+                    c->d_testctr, c->d_ovf, c->d_sortkeys, c->d_sortperm, c->d_sorthist,
+                    c->d_lbvh, c->d_lbvh_nodes, c->d_lbvh_s2s};
     for (void* p : ptrs) if (p) hipFree(p);
     for (uint32_t* q : c->tl_ids) if (q) hipFree(q);
     for (hipEvent_t e : c->evpool) hipEventDestroy(e);
@@ -427,11 +431,74 @@ int crt_lights_set(crt_ctx* c, const crt_light* lights, int n) {
     return CRT_OK;
 }
 
+/* CRT_BVH_WIDE_DEVICE: lbvh.hip builds Node8 records from the device copy of the scene; the blob is laid out
+ * once the node count is known, and from there on it is an ordinary wide-mode blob. */
+static int build_on_device(crt_ctx* c) {
+    const uint32_t n = (uint32_t)c->prims.size();
+    auto t0 = std::chrono::steady_clock::now();
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    const size_t need = lbvh_scratch_bytes(n);
+    if (need > c->lbvh_cap || !c->d_lbvh) {
+        if (c->d_lbvh) HIPCHECK(c, hipFree(c->d_lbvh));
+        c->d_lbvh = nullptr;
+        HIPCHECK(c, hipMalloc(&c->d_lbvh, need + need / 8));
+        c->lbvh_cap = need + need / 8;
+    }
+    int rc;
+    if ((rc = ensure(c, c->d_lbvh_nodes, c->lbvh_nodes_cap, (size_t)n))) return rc;
+    if ((rc = ensure(c, c->d_lbvh_s2s, c->lbvh_s2s_cap, (size_t)n))) return rc;
+    uint32_t nnodes = 0, depth = 0;
+    float root_box[6];
+    std::string err;
+    rc = lbvh_build(c->d_lbvh, c->d_prims, n, c->d_lbvh_nodes, n, c->d_lbvh_s2s, &nnodes, &depth, root_box, c->stream, &err);
+    if (rc) return fail(c, rc, err.c_str());
+
+    BlobHeader h{};
+    h.magic = kBlobMagic; h.version = kBlobVersion;
+    h.nprims = n; h.nnodes = nnodes; h.nmats = (uint32_t)c->mats.size();
+    h.depth = depth; h.mode = CRT_BVH_WIDE;
+    memcpy(h.root_box, root_box, sizeof h.root_box);
+    layout_blob(h);
+    if (h.total_bytes > c->blob_cap || !c->d_blob) {
+        if (c->d_blob) HIPCHECK(c, hipFree(c->d_blob));
+        c->d_blob = nullptr;
+        HIPCHECK(c, hipMalloc(&c->d_blob, h.total_bytes));
+        c->blob_cap = h.total_bytes;
+    }
+    c->blob_bytes = h.total_bytes; c->hdr = h;
+    char* b = (char*)c->d_blob;
+    HIPCHECK(c, hipMemcpyAsync(b, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(b + h.off_nodes, c->d_lbvh_nodes, (size_t)nnodes * sizeof(Node8), hipMemcpyDeviceToDevice, c->stream));
+    launch_lbvh_maps(c->d_lbvh_s2s, n, (uint32_t*)(b + h.off_sidx), (uint32_t*)(b + h.off_slot_of), (uint32_t*)(b + h.off_rank), c->stream);
+    if (h.nmats) HIPCHECK(c, hipMemcpyAsync(b + h.off_mats, c->mats.data(), (size_t)h.nmats * sizeof(Material), hipMemcpyHostToDevice, c->stream));
+    launch_pack_prims(c->d_prims, c->d_matid, (const uint32_t*)(b + h.off_slot_of), n, (Geom*)(b + h.off_geom), (Shade*)(b + h.off_shade), c->stream);
+    launch_quantize((const Node8*)(b + h.off_nodes), h.nnodes, (QNode8*)(b + h.off_qnodes), c->d_status, c->stream);
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    rc = check_status(c);
+    if (rc) return rc;
+    rc = ensure(c, c->d_arrive, c->arrive_cap, (size_t)h.nnodes + 1);
+    if (rc) return rc;
+    scene_abs_from_box(c);
+    rc = size_overflow(c);
+    if (rc) return rc;
+    c->built = true; c->have_ref = false;
+    c->ref = RefTree(); c->bvh = HostBVH();
+    c->stats.nodes = (int)h.nnodes; c->stats.prims = (int)n; c->stats.depth = (int)h.depth; c->stats.leaves = (int)n;
+    c->stats.scene_bytes = h.total_bytes;
+    c->stats.ms_build_device = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return CRT_OK;
+}
+
 int crt_bvh_build(crt_ctx* c, int mode) {
     if (!c) return CRT_ERR_ARG;
-    if (mode != CRT_BVH_WIDE && mode != CRT_BVH_REFERENCE) return fail(c, CRT_ERR_ARG, "crt_bvh_build: unknown mode");
+    if (mode != CRT_BVH_WIDE && mode != CRT_BVH_REFERENCE && mode != CRT_BVH_WIDE_DEVICE) return fail(c, CRT_ERR_ARG, "crt_bvh_build: unknown mode");
     if (c->imported) return fail(c, CRT_ERR_STATE, "crt_bvh_build: scene was imported as a blob");
     HIPCHECK(c, hipSetDevice(c->device));
+    if (mode == CRT_BVH_WIDE_DEVICE) {
+        if (!c->prims.empty()) return build_on_device(c);
+        mode = CRT_BVH_WIDE;                 /* nothing to sort: the host path writes the empty root */
+    }
     const int n = (int)c->prims.size();
     if (c->host_stale) {          /* the scene was animated on the device: the host builders need its current state */
         HIPCHECK(c, hipMemcpyAsync(c->prims.data(), c->d_prims, (size_t)n * sizeof(crt_prim), hipMemcpyDeviceToHost, c->stream));

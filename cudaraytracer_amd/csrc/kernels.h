@@ -4,6 +4,7 @@
 #define CRT_KERNELS_H
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string>
 #include "layout.h"
 #include "../../include/crt.h"
 
@@ -115,6 +116,12 @@ constexpr int kSortBits = 5;
 constexpr int kSortBins = 1 << (3 * kSortBits);
 void launch_sort_rays(const float4* rayO, const uint32_t* count, uint32_t cap, const float* root_box6, uint32_t* keys,
                       uint32_t* hist, uint32_t* perm, hipStream_t s);
+/* device-side build of the wide tree (lbvh.hip): scratch sized by lbvh_scratch_bytes(n); nodes_out holds up to
+ * node_cap (>= n) Node8 records, slot_to_scene n words; the node count and depth come back to the host */
+size_t lbvh_scratch_bytes(uint32_t n);
+int lbvh_build(void* scratch, const crt_prim* d_prims, uint32_t n, Node8* nodes_out, uint32_t node_cap, uint32_t* slot_to_scene,
+               uint32_t* h_nnodes, uint32_t* h_depth, float root_box[6], hipStream_t s, std::string* err);
+void launch_lbvh_maps(const uint32_t* slot_to_scene, uint32_t n, uint32_t* sidx, uint32_t* slot_of, uint32_t* rank, hipStream_t s);
 struct AnimParam { float m[16]; };          /* column-major rotation of main.cu:548 */
 void animation_matrix(float out16[16]);     /* scene.cpp */
 void launch_animate(crt_prim* d_prims, uint32_t n, const AnimParam& a, hipStream_t s);

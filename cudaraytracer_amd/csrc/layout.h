@@ -37,6 +37,9 @@ constexpr uint32_t kLeafStartMask = (1u << kLeafCountShift) - 1u;
 constexpr int kMaxLeafPrims = 64;
 
 /* leaf link: bit31 | (count-1) << 25 | first slot */
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
 static inline uint32_t make_leaf(uint32_t start, uint32_t count) {
     return kLeafFlag | ((count - 1u) << kLeafCountShift) | start;
 }

@@ -1,0 +1,384 @@
+/* lbvh.hip -- device-side build of the 8-wide tree (CRT_BVH_WIDE_DEVICE).
+ *
+ * The host builders (bvh_build.cpp) take about a second for a million primitives; "rebuild every N
+ * frames" (main.cu:534-541) on a large animated scene needs the rebuild on the device.  This is a
+ * linear BVH: 30-bit Morton codes of the primitive centres, radix sort (rocPRIM), the binary radix
+ * tree of Karras 2012 built with one thread per internal node, boxes fitted bottom-up with arrival
+ * counters, then a level-by-level collapse into the same Node8 records the SAH builder produces
+ * (largest-area child opened first, children in octant slots, internal children consecutive, leaf
+ * primitives in one consecutive slot range) -- so refit, quantiser and traversal are shared.
+ * Leaves hold one primitive.  There is no reference-topology pass in this mode: exact-t ties
+ * resolve by scene index instead of the reference's leaf order (SURVEY.md 9.1 class G2).
+ */
+#include <cstring>
+#include <string>
+#include "kernels.h"
+#include "vec.h"
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace crt {
+
+namespace {
+
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kNone = 0xffffffffu;
+enum { CTR_NODES = 0, CTR_SLOTS, CTR_QUEUE_A, CTR_QUEUE_B, CTR_DEPTH, CTR_WORDS = 8 };
+
+struct QItem { uint32_t b, w, parent, pslot_depth; };     /* binary node, wide node, wide parent, slot | depth << 8 */
+
+struct Scratch {
+    float4 *plo, *phi;            /* primitive boxes, scene order */
+    float4 *ilo, *ihi;            /* boxes of the binary internal nodes */
+    uint32_t *keys, *keys2, *vals, *vals2;
+    uint32_t *left, *right;       /* children of the binary internal nodes: index | kLeafBit */
+    uint32_t *parent;             /* [0, n-1): of internal nodes; [n-1, 2n-1): of leaves */
+    uint32_t *flags;
+    uint32_t *ctr;
+    int32_t *cbox;                /* centre bounds as ordered ints: lo xyz, hi xyz */
+    QItem *qa, *qb;
+    void* sort_tmp; size_t sort_tmp_bytes;
+};
+
+inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+size_t sort_temp_bytes(uint32_t n) {
+    size_t bytes = 0;
+    uint32_t* k = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, k, k, (size_t)n, 0u, 30u, (hipStream_t)0);
+    return bytes;
+}
+
+Scratch carve(void* base, uint32_t n, size_t* total) {
+    Scratch s{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { void* p = base ? (char*)base + off : nullptr; off += up256(bytes); return p; };
+    const size_t nn = n ? n : 1;
+    s.plo = (float4*)take(nn * 16); s.phi = (float4*)take(nn * 16);
+    s.ilo = (float4*)take(nn * 16); s.ihi = (float4*)take(nn * 16);
+    s.keys = (uint32_t*)take(nn * 4); s.keys2 = (uint32_t*)take(nn * 4);
+    s.vals = (uint32_t*)take(nn * 4); s.vals2 = (uint32_t*)take(nn * 4);
+    s.left = (uint32_t*)take(nn * 4); s.right = (uint32_t*)take(nn * 4);
+    s.parent = (uint32_t*)take(nn * 8);
+    s.flags = (uint32_t*)take(nn * 4);
+    s.ctr = (uint32_t*)take(CTR_WORDS * 4);
+    s.cbox = (int32_t*)take(6 * 4);
+    s.qa = (QItem*)take(nn * sizeof(QItem)); s.qb = (QItem*)take(nn * sizeof(QItem));
+    s.sort_tmp_bytes = sort_temp_bytes(n);
+    s.sort_tmp = take(s.sort_tmp_bytes + 256);
+    if (total) *total = off;
+    return s;
+}
+
+/* order-preserving float <-> int for atomicMin / atomicMax */
+__device__ __forceinline__ int32_t f2ord(float f) { const int32_t i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+__device__ __forceinline__ float ord2f(int32_t i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+__global__ __launch_bounds__(256) void k_lbvh_bounds(const crt_prim* prims, uint32_t n, float4* plo, float4* phi, int32_t* cbox) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    float lo[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, hi[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+    if (i < n) {
+        const crt_prim& o = prims[i];
+        if (o.type == 0) {
+            for (int a = 0; a < 3; a++) { lo[a] = o.position[a] - o.radius; hi[a] = o.position[a] + o.radius; }
+        } else {
+            for (int a = 0; a < 3; a++) {
+                lo[a] = fminf(o.v1[a], fminf(o.v2[a], o.v3[a]));
+                hi[a] = fmaxf(o.v1[a], fmaxf(o.v2[a], o.v3[a]));
+            }
+        }
+        plo[i] = make_float4(lo[0], lo[1], lo[2], 0.f);
+        phi[i] = make_float4(hi[0], hi[1], hi[2], 0.f);
+    }
+    /* bounds of the box centres: wave reduction, then one atomic per wave and component */
+    for (int a = 0; a < 3; a++) {
+        float c = 0.5f * (lo[a] + hi[a]);
+        float cmin = i < n ? c : 3.402823466e+38f, cmax = i < n ? c : -3.402823466e+38f;
+        for (int off = 32; off > 0; off >>= 1) {
+            cmin = fminf(cmin, __shfl_xor(cmin, off));
+            cmax = fmaxf(cmax, __shfl_xor(cmax, off));
+        }
+        if ((threadIdx.x & 63u) == 0u && cmin <= cmax) {
+            atomicMin(&cbox[a], f2ord(cmin));
+            atomicMax(&cbox[3 + a], f2ord(cmax));
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t expand10(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_lbvh_morton(const float4* plo, const float4* phi, uint32_t n, const int32_t* cbox,
+                                                      uint32_t* keys, uint32_t* vals) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 lo = plo[i], hi = phi[i];
+    const float c[3] = {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
+    uint32_t q[3];
+    for (int a = 0; a < 3; a++) {
+        const float l = ord2f(cbox[a]), h = ord2f(cbox[3 + a]);
+        const float ext = h - l;
+        float t = ext > 0.f ? (c[a] - l) / ext * 1024.0f : 0.f;
+        t = fminf(fmaxf(t, 0.f), 1023.0f);
+        q[a] = (uint32_t)t;
+    }
+    keys[i] = (expand10(q[0]) << 2) | (expand10(q[1]) << 1) | expand10(q[2]);
+    vals[i] = i;
+}
+
+__device__ __forceinline__ int delta(const uint32_t* k, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const uint32_t a = k[i], b = k[j];
+    if (a == b) return 32 + __clz((int)((uint32_t)i ^ (uint32_t)j));
+    return __clz((int)(a ^ b));
+}
+
+/* Karras 2012, one thread per internal node */
+__global__ __launch_bounds__(256) void k_lbvh_tree(const uint32_t* k, int n, uint32_t* left, uint32_t* right, uint32_t* parent) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n - 1) return;
+    const int d = (delta(k, n, i, i + 1) - delta(k, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = delta(k, n, i, i - d);
+    int lmax = 2;
+    while (delta(k, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (delta(k, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = delta(k, n, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (delta(k, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + (d < 0 ? d : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const bool lleaf = lo == gamma, rleaf = hi == gamma + 1;
+    left[i] = lleaf ? ((uint32_t)gamma | kLeafBit) : (uint32_t)gamma;
+    right[i] = rleaf ? ((uint32_t)(gamma + 1) | kLeafBit) : (uint32_t)(gamma + 1);
+    parent[lleaf ? (n - 1 + gamma) : gamma] = (uint32_t)i;
+    parent[rleaf ? (n - 1 + gamma + 1) : (gamma + 1)] = (uint32_t)i;
+    if (i == 0) parent[0] = kNone;
+}
+
+/* boxes bottom-up: the second child to arrive at a node (agent-scope counter) carries on */
+__global__ __launch_bounds__(256) void k_lbvh_fit(const float4* plo, const float4* phi, const uint32_t* vals, int n, const uint32_t* left,
+                                                   const uint32_t* right, const uint32_t* parent, uint32_t* flags, float4* ilo, float4* ihi) {
+    const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (j >= n) return;
+    uint32_t node = parent[n - 1 + j];
+    for (int guard = 0; guard < 4096 && node != kNone; guard++) {
+        const uint32_t prev = __hip_atomic_fetch_add(&flags[node], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == 0u) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t cl = left[node], cr = right[node];
+        const float4 al = (cl & kLeafBit) ? plo[vals[cl & ~kLeafBit]] : ilo[cl];
+        const float4 ah = (cl & kLeafBit) ? phi[vals[cl & ~kLeafBit]] : ihi[cl];
+        const float4 bl = (cr & kLeafBit) ? plo[vals[cr & ~kLeafBit]] : ilo[cr];
+        const float4 bh = (cr & kLeafBit) ? phi[vals[cr & ~kLeafBit]] : ihi[cr];
+        ilo[node] = make_float4(fminf(al.x, bl.x), fminf(al.y, bl.y), fminf(al.z, bl.z), 0.f);
+        ihi[node] = make_float4(fmaxf(ah.x, bh.x), fmaxf(ah.y, bh.y), fmaxf(ah.z, bh.z), 0.f);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        node = parent[node];
+    }
+}
+
+__device__ __forceinline__ float box_area(const float4& lo, const float4& hi) {
+    const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+    return 2.f * (dx * dy + dy * dz + dz * dx);
+}
+
+/* one level of the collapse: every queue item becomes one Node8 */
+__global__ __launch_bounds__(128) void k_lbvh_collapse(const QItem* qin, const uint32_t* qin_count, QItem* qout, uint32_t* qout_count,
+                                                        uint32_t* ctr, const float4* plo, const float4* phi, const float4* ilo, const float4* ihi,
+                                                        const uint32_t* vals, const uint32_t* left, const uint32_t* right, Node8* nodes,
+                                                        uint32_t node_cap, uint32_t* slot_to_scene, uint32_t nprims) {
+    const uint32_t total = *qin_count;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
+        const QItem it = qin[q];
+        uint32_t kids[8];
+        int nk = 0;
+        kids[nk++] = left[it.b]; kids[nk++] = right[it.b];
+        while (nk < 8) {                      /* open the internal child with the largest surface area */
+            int best = -1; float bestA = -1.f;
+            for (int k = 0; k < nk; k++) {
+                if (kids[k] & kLeafBit) continue;
+                const float a = box_area(ilo[kids[k]], ihi[kids[k]]);
+                if (a > bestA) { bestA = a; best = k; }
+            }
+            if (best < 0) break;
+            const uint32_t c = kids[best];
+            kids[best] = left[c];
+            kids[nk++] = right[c];
+        }
+        float4 klo[8], khi[8];
+        for (int k = 0; k < nk; k++) {
+            if (kids[k] & kLeafBit) { const uint32_t p = vals[kids[k] & ~kLeafBit]; klo[k] = plo[p]; khi[k] = phi[p]; }
+            else { klo[k] = ilo[kids[k]]; khi[k] = ihi[kids[k]]; }
+        }
+        /* octant slots (as build_wide): greedy (child, slot) pairs by the projection of the child's offset on the slot diagonal */
+        const float4 nlo = ilo[it.b], nhi = ihi[it.b];
+        const float cx = 0.5f * (nlo.x + nhi.x), cy = 0.5f * (nlo.y + nhi.y), cz = 0.5f * (nlo.z + nhi.z);
+        int kid_at[8];
+        for (int s = 0; s < 8; s++) kid_at[s] = -1;
+        uint32_t done = 0, used = 0;
+        for (int round = 0; round < nk; round++) {
+            int bi = -1, bs = -1; float bc = -3.402823466e+38f;
+            for (int i = 0; i < nk; i++) {
+                if (done & (1u << i)) continue;
+                const float vx = 0.5f * (klo[i].x + khi[i].x) - cx, vy = 0.5f * (klo[i].y + khi[i].y) - cy, vz = 0.5f * (klo[i].z + khi[i].z) - cz;
+                for (int s = 0; s < 8; s++) {
+                    if (used & (1u << s)) continue;
+                    const float c = ((s & 4) ? vx : -vx) + ((s & 2) ? vy : -vy) + ((s & 1) ? vz : -vz);
+                    if (c > bc || bi < 0) { bc = c; bi = i; bs = s; }
+                }
+            }
+            done |= 1u << bi; used |= 1u << bs; kid_at[bs] = bi;
+        }
+        uint32_t ni = 0, nl = 0;
+        for (int k = 0; k < nk; k++) { if (kids[k] & kLeafBit) nl++; else ni++; }
+        const uint32_t cbase = ni ? atomicAdd(&ctr[CTR_NODES], ni) : 0u;
+        const uint32_t pbase = nl ? atomicAdd(&ctr[CTR_SLOTS], nl) : 0u;
+        const uint32_t qbase = ni ? atomicAdd(qout_count, ni) : 0u;
+        const uint32_t depth = it.pslot_depth >> 8;
+        atomicMax(&ctr[CTR_DEPTH], depth);
+        if (it.w >= node_cap || cbase + ni > node_cap || pbase + nl > nprims) continue;       /* cannot happen: caps are n and n */
+        Node8 nd;
+        for (int s = 0; s < 8; s++) {
+            nd.lox[s] = nd.loy[s] = nd.loz[s] = 3.402823466e+38f;
+            nd.hix[s] = nd.hiy[s] = nd.hiz[s] = -3.402823466e+38f;
+            nd.child[s] = kChildEmpty;
+        }
+        nd.parent = it.parent; nd.parent_slot = it.pslot_depth & 0xffu; nd.n_internal = ni; nd.pad = 0;
+        nd.pad2[0] = nd.pad2[1] = nd.pad2[2] = nd.pad2[3] = 0;
+        uint32_t ii = 0, li = 0;
+        for (int s = 0; s < 8; s++) {
+            const int k = kid_at[s];
+            if (k < 0) continue;
+            nd.lox[s] = klo[k].x; nd.loy[s] = klo[k].y; nd.loz[s] = klo[k].z;
+            nd.hix[s] = khi[k].x; nd.hiy[s] = khi[k].y; nd.hiz[s] = khi[k].z;
+            if (kids[k] & kLeafBit) {
+                slot_to_scene[pbase + li] = vals[kids[k] & ~kLeafBit];
+                nd.child[s] = make_leaf(pbase + li, 1u);
+                li++;
+            } else {
+                nd.child[s] = cbase + ii;
+                QItem c; c.b = kids[k]; c.w = cbase + ii; c.parent = it.w; c.pslot_depth = (uint32_t)s | ((depth + 1u) << 8);
+                qout[qbase + ii] = c;
+                ii++;
+            }
+        }
+        nodes[it.w] = nd;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lbvh_maps(const uint32_t* slot_to_scene, uint32_t n, uint32_t* sidx, uint32_t* slot_of, uint32_t* rank) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const uint32_t si = slot_to_scene[s];
+    sidx[s] = si; slot_of[si] = s; rank[s] = si;        /* ties resolve by scene index in this mode */
+}
+
+/* n == 1: a root whose only child is the leaf */
+__global__ void k_lbvh_single(const float4* plo, const float4* phi, Node8* nodes, uint32_t* slot_to_scene) {
+    Node8 nd;
+    for (int s = 0; s < 8; s++) {
+        nd.lox[s] = nd.loy[s] = nd.loz[s] = 3.402823466e+38f;
+        nd.hix[s] = nd.hiy[s] = nd.hiz[s] = -3.402823466e+38f;
+        nd.child[s] = kChildEmpty;
+    }
+    nd.parent = kChildEmpty; nd.parent_slot = 0; nd.n_internal = 0; nd.pad = 0;
+    nd.pad2[0] = nd.pad2[1] = nd.pad2[2] = nd.pad2[3] = 0;
+    nd.lox[0] = plo[0].x; nd.loy[0] = plo[0].y; nd.loz[0] = plo[0].z;
+    nd.hix[0] = phi[0].x; nd.hiy[0] = phi[0].y; nd.hiz[0] = phi[0].z;
+    nd.child[0] = make_leaf(0u, 1u);
+    slot_to_scene[0] = 0;
+    nodes[0] = nd;
+}
+
+}  // namespace
+
+size_t lbvh_scratch_bytes(uint32_t n) {
+    size_t total = 0;
+    (void)carve(nullptr, n, &total);
+    return total;
+}
+
+#define LB(call)                                                                                   \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) { if (err) *err = std::string(#call) + ": " + hipGetErrorString(e_); return CRT_ERR_HIP; } \
+    } while (0)
+
+void launch_lbvh_maps(const uint32_t* slot_to_scene, uint32_t n, uint32_t* sidx, uint32_t* slot_of, uint32_t* rank, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_lbvh_maps, dim3((n + 255u) / 256u), dim3(256), 0, s, slot_to_scene, n, sidx, slot_of, rank);
+}
+
+int lbvh_build(void* scratch, const crt_prim* d_prims, uint32_t n, Node8* nodes_out, uint32_t node_cap, uint32_t* slot_to_scene,
+               uint32_t* h_nnodes, uint32_t* h_depth, float root_box[6], hipStream_t s, std::string* err) {
+    if (n == 0 || node_cap == 0) { if (err) *err = "lbvh_build: empty scene"; return CRT_ERR_ARG; }
+    Scratch S = carve(scratch, n, nullptr);
+    const uint32_t blocks = (n + 255u) / 256u;
+    const int32_t big = 0x7f7fffff;       /* ordered int of +FLT_MAX; its negation orders as -FLT_MAX */
+    const int32_t init[6] = {big, big, big, -big, -big, -big};
+    LB(hipMemcpyAsync(S.cbox, init, sizeof init, hipMemcpyHostToDevice, s));
+    LB(hipMemsetAsync(S.ctr, 0, CTR_WORDS * 4, s));
+    hipLaunchKernelGGL(k_lbvh_bounds, dim3(blocks), dim3(256), 0, s, d_prims, n, S.plo, S.phi, S.cbox);
+    if (n == 1) {
+        hipLaunchKernelGGL(k_lbvh_single, dim3(1), dim3(1), 0, s, S.plo, S.phi, nodes_out, slot_to_scene);
+        float4 lo, hi;
+        LB(hipMemcpyAsync(&lo, S.plo, 16, hipMemcpyDeviceToHost, s));
+        LB(hipMemcpyAsync(&hi, S.phi, 16, hipMemcpyDeviceToHost, s));
+        LB(hipStreamSynchronize(s));
+        root_box[0] = lo.x; root_box[1] = hi.x; root_box[2] = lo.y; root_box[3] = hi.y; root_box[4] = lo.z; root_box[5] = hi.z;
+        *h_nnodes = 1; *h_depth = 1;
+        return CRT_OK;
+    }
+    hipLaunchKernelGGL(k_lbvh_morton, dim3(blocks), dim3(256), 0, s, S.plo, S.phi, n, S.cbox, S.keys, S.vals);
+    size_t tmp = S.sort_tmp_bytes;
+    LB(rocprim::radix_sort_pairs(S.sort_tmp, tmp, S.keys, S.keys2, S.vals, S.vals2, (size_t)n, 0u, 30u, s));
+    LB(hipMemsetAsync(S.flags, 0, (size_t)n * 4, s));
+    hipLaunchKernelGGL(k_lbvh_tree, dim3(blocks), dim3(256), 0, s, S.keys2, (int)n, S.left, S.right, S.parent);
+    hipLaunchKernelGGL(k_lbvh_fit, dim3(blocks), dim3(256), 0, s, S.plo, S.phi, S.vals2, (int)n, S.left, S.right, S.parent, S.flags, S.ilo, S.ihi);
+    /* collapse, one launch per level; the level sizes come back to the host (a build is not a per-frame operation) */
+    QItem root; root.b = 0; root.w = 0; root.parent = kChildEmpty; root.pslot_depth = (1u << 8);
+    uint32_t one = 1;
+    LB(hipMemcpyAsync(S.qa, &root, sizeof root, hipMemcpyHostToDevice, s));
+    LB(hipMemcpyAsync(S.ctr + CTR_QUEUE_A, &one, 4, hipMemcpyHostToDevice, s));
+    LB(hipMemcpyAsync(S.ctr + CTR_NODES, &one, 4, hipMemcpyHostToDevice, s));
+    uint32_t level_count = 1;
+    int cur = 0;
+    for (int level = 0; level < 512 && level_count > 0; level++) {
+        QItem* qin = cur ? S.qb : S.qa; QItem* qout = cur ? S.qa : S.qb;
+        uint32_t* cin = S.ctr + (cur ? CTR_QUEUE_B : CTR_QUEUE_A); uint32_t* cout = S.ctr + (cur ? CTR_QUEUE_A : CTR_QUEUE_B);
+        LB(hipMemsetAsync(cout, 0, 4, s));
+        uint32_t gb = (level_count + 127u) / 128u;
+        if (gb > 4096u) gb = 4096u;
+        hipLaunchKernelGGL(k_lbvh_collapse, dim3(gb), dim3(128), 0, s, qin, cin, qout, cout, S.ctr, S.plo, S.phi, S.ilo, S.ihi, S.vals2,
+                           S.left, S.right, nodes_out, node_cap, slot_to_scene, n);
+        LB(hipMemcpyAsync(&level_count, cout, 4, hipMemcpyDeviceToHost, s));
+        LB(hipStreamSynchronize(s));
+        cur ^= 1;
+    }
+    LB(hipGetLastError());
+    uint32_t h[CTR_WORDS];
+    float4 rlo, rhi;
+    LB(hipMemcpyAsync(h, S.ctr, sizeof h, hipMemcpyDeviceToHost, s));
+    LB(hipMemcpyAsync(&rlo, S.ilo, 16, hipMemcpyDeviceToHost, s));
+    LB(hipMemcpyAsync(&rhi, S.ihi, 16, hipMemcpyDeviceToHost, s));
+    LB(hipStreamSynchronize(s));
+    if (level_count != 0 || h[CTR_SLOTS] != n || h[CTR_NODES] > node_cap) { if (err) *err = "lbvh_build: collapse did not place every primitive"; return CRT_ERR_BUILD; }
+    root_box[0] = rlo.x; root_box[1] = rhi.x; root_box[2] = rlo.y; root_box[3] = rhi.y; root_box[4] = rlo.z; root_box[5] = rhi.z;
+    *h_nnodes = h[CTR_NODES]; *h_depth = h[CTR_DEPTH];
+    return CRT_OK;
+}
+#undef LB
+
+}  // namespace crt

@@ -90,6 +90,7 @@ typedef struct crt_stats {
     double ms_build_host, ms_refit;
     uint64_t scene_bytes;    /* packed scene + BVH bytes resident in HBM */
     uint64_t node_visits, node_visits_shadow;   /* counting only: BVH nodes visited (one visit tests all its children) */
+    double ms_build_device;  /* wall time of the last CRT_BVH_WIDE_DEVICE build */
 } crt_stats;
 
 typedef struct crt_ctx crt_ctx;
@@ -117,6 +118,10 @@ int crt_scene_get(crt_ctx*, crt_prim* prims_out, int n);        /* current scene
  *      (bvh.cu:288-400) and freeTree (bvh.cu:274-286) ---- */
 #define CRT_BVH_WIDE 0       /* binned-SAH tree collapsed to compressed 8-wide nodes, <=4 primitives per leaf */
 #define CRT_BVH_REFERENCE 1  /* the reference's topology (mean-centroid split, <=64 per leaf), exact boxes */
+#define CRT_BVH_WIDE_DEVICE 2 /* the same 8-wide format built on the device (Morton-order linear BVH, one primitive per leaf):
+                              * milliseconds instead of a second for 1M primitives, for "rebuild every N frames" on large
+                              * animated scenes.  Builds from the device copy of the scene (after crt_animate_device no
+                              * copy back); no reference-order pass: exact-t ties resolve by scene index */
 int crt_bvh_build(crt_ctx*, int mode);
 #define CRT_REFIT_TIGHT 0
 #define CRT_REFIT_GROW 1     /* boxes only grow, as refitTree does */
