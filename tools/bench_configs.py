@@ -55,8 +55,9 @@ def teapot(width, height, bounces, name, threads):
     print(json.dumps(out), flush=True)
 
 
-def spheres(n=4096, frames=60, width=1920, height=1080, bounces=2):
-    prims = crt.scene_spheres(n, seed=1)
+def spheres(n=4096, frames=60, width=1920, height=1080, bounces=2, rebuild_mode=0, prims=None, label=None):
+    if prims is None:
+        prims = crt.scene_spheres(n, seed=1)
     lights = crt.default_lights(); cam, tgt = crt.default_camera()
     ctx = crt.Context(0); ctx.set_scene(prims); ctx.set_lights(lights); ctx.build(0)
     p = crt.default_params(width=width, height=height, bounces=bounces)
@@ -66,7 +67,7 @@ def spheres(n=4096, frames=60, width=1920, height=1080, bounces=2):
         t0 = time.perf_counter()
         ctx.animate_device()
         if f % 20 == 0:
-            ctx.build(0); kinds.append("rebuild")           # host SAH build + upload
+            ctx.build(rebuild_mode); kinds.append("rebuild")   # 0: host SAH build + upload, 2: LBVH on the device
         else:
             ctx.refit(False); kinds.append("refit")
         ctx.sync()
@@ -74,8 +75,8 @@ def spheres(n=4096, frames=60, width=1920, height=1080, bounces=2):
         ctx.render_device(cam, tgt, p)
         st = ctx.stats(); ren.append(st["ms_total"]); rays = rays_of(st)
     upd = np.array(upd); ren = np.array(ren); is_rb = np.array([k == "rebuild" for k in kinds])
-    print(json.dumps({"config": f"configs[2]: {n} animated spheres, {width}x{height}, bounces={bounces}, {frames} frames, "
-                                "device animation + refit every frame, host rebuild every 20th",
+    print(json.dumps({"config": (label or f"configs[2]: {n} animated spheres") + f", {width}x{height}, bounces={bounces}, {frames} frames, "
+                                "device animation + refit every frame, " + ("host SAH" if rebuild_mode == 0 else "device LBVH") + " rebuild every 20th",
                       "render_ms_mean": round(float(ren.mean()), 4), "render_ms_worst": round(float(ren.max()), 4),
                       "update_ms_refit_mean": round(float(upd[~is_rb].mean()), 4), "update_ms_refit_worst": round(float(upd[~is_rb].max()), 4),
                       "update_ms_rebuild_mean": round(float(upd[is_rb].mean()), 4),
@@ -102,12 +103,17 @@ def soup_8k_one_rank(nranks=8, spp=16):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["0", "1", "2", "4"]
+    which = sys.argv[1:] or ["0", "1", "2", "2big", "4"]
     if "0" in which:
         teapot(720, 360, 1, "configs[0]: teapot3.obj + sphere, 720x360, bounces=1 (no reflection)", (1, 16))
     if "1" in which:
         teapot(1920, 1080, 4, "configs[1]: teapot3.obj + sphere, 1920x1080, reflection depth 3 (bounces=4)", (16,))
     if "2" in which:
         spheres()
+        spheres(rebuild_mode=2)
+    if "2big" in which:       # the animation loop on the 1M-triangle soup: only feasible with the device rebuild
+        soup = crt.scene_soup(1000000, seed=1)
+        spheres(frames=40, width=3840, height=2160, bounces=3, rebuild_mode=2, prims=soup, label="animation loop on the 1M-triangle soup")
+        spheres(frames=21, width=3840, height=2160, bounces=3, rebuild_mode=0, prims=soup, label="animation loop on the 1M-triangle soup")
     if "4" in which:
         soup_8k_one_rank()
