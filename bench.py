@@ -103,6 +103,12 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         a.gpus = world
 
+    dist = torch = None
+    if world > 1:
+        # torch BEFORE the library: PyTorch bundles its own HIP runtime, and a process that loads libcrt_amd.so (system
+        # runtime) first and torch second ends up with two runtimes, the second of which finds no device
+        import torch
+        import torch.distributed as dist
     import cudaraytracer_amd as crt
 
     cam, tgt = crt.default_camera()
@@ -112,12 +118,16 @@ def main():
     prims = crt.scene_soup(a.tris, seed=1) if (rank == 0 or world == 1) else None
     log(f"scene generated: {a.tris} triangles")
 
-    dist = torch = None
     if world > 1:
-        import torch
-        import torch.distributed as dist
+        # rehearsal on a one-GPU box: CRT_DIST_BACKEND=gloo CRT_FORCE_DEVICE=0 puts every rank on one device
+        backend = os.environ.get("CRT_DIST_BACKEND", "nccl")
+        if "CRT_FORCE_DEVICE" in os.environ:
+            local_rank = int(os.environ["CRT_FORCE_DEVICE"])
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
         from cudaraytracer_amd.parallel import ShardedRenderer
         sr = ShardedRenderer(dist, torch, rank, world, local_rank)
         sr.broadcast_scene(prims, lights, a.bvh)

@@ -242,7 +242,15 @@ class Context:
         err = _i(0)
         self.h = lib.crt_create(device, C.byref(err))
         if not self.h:
-            raise CrtError(err.value, "crt_create failed (no HIP device?)")
+            hint = ""
+            try:
+                libs = {l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l}
+                if len(libs) > 1:
+                    hint = (" -- two HIP runtimes are loaded (" + ", ".join(sorted(libs)) + "): import torch BEFORE "
+                            "cudaraytracer_amd so that both use the one PyTorch bundles")
+            except OSError:
+                pass
+            raise CrtError(err.value, "crt_create failed (no HIP device?)" + hint)
         self.nprims = 0
 
     def close(self):

@@ -534,7 +534,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
                         }
                         /* 32-bit byte offsets from the uniform base (nodes < 2^24): scalar base + vector offset addressing */
                         static_assert(sizeof(QNode8) == 80, "node * 80 below");
-                        const uint4* np = reinterpret_cast<const uint4*>(qbase + ((node << 6) + (node << 4)));
+                        const uint4* np = reinterpret_cast<const uint4*>(qbase + __umul24(node, 80u));     /* v_mul_u32_u24: full rate, nodes < 2^24 */
                         const uint4 h0 = np[0], h1 = np[1];
                         const uint4 PX = np[2], PY = np[3], PZ = np[4];       /* lo_x[8] hi_x[8] | lo_y hi_y | lo_z hi_z */
                         const uint32_t em = h0.w;

@@ -6,6 +6,8 @@ rehearsal in tests).  Pixels are independent, so the only exchanges are
   2. gather of each rank's tile pixels (BGR8, tile-major) to rank 0, which scatters them into
      the bottom-up frame.
 There is no reduction anywhere.  torch is used for the device buffers and the collectives only.
+Import torch BEFORE this package: PyTorch bundles its own HIP runtime, and loading libcrt_amd.so
+(system runtime) first leaves the process with two runtimes, the second without a device.
 
 The tile -> rank map and the tile-major packing are defined by the C ABI (crt_tile_owner,
 crt_tiles_owned, crt_tiles_pack/unpack); `pack_tiles_host` / `unpack_tiles_host` restate the same
@@ -84,6 +86,8 @@ class ShardedRenderer:
         self._hip = C.CDLL("libamdhip64.so")
         self._hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         self._hip.hipMemcpy.restype = C.c_int
+        # RCCL gathers device tensors directly; gloo (the one-GPU rehearsal) has no device gather, so stage through the host
+        self.host_gather = dist.get_backend() != "nccl"
         self.frame = None
         self.packed = None
         self.gathered = None
@@ -140,7 +144,15 @@ class ShardedRenderer:
         if self.world == 1:
             return self.frame
         self.ctx.tiles_pack(params, self.frame.data_ptr(), self.packed.data_ptr())
-        self.dist.gather(self.packed, self.gathered, dst=0)
+        if self.host_gather:
+            mine = self.packed.cpu()
+            got = [self.torch.zeros_like(mine) for _ in range(self.world)] if self.rank == 0 else None
+            self.dist.gather(mine, got, dst=0)
+            if self.rank == 0:
+                for r in range(1, self.world):
+                    self.gathered[r].copy_(got[r])
+        else:
+            self.dist.gather(self.packed, self.gathered, dst=0)
         if self.rank == 0:
             self.torch.cuda.synchronize(self.dev)
             for r in range(1, self.world):

@@ -1,0 +1,34 @@
+"""One rank of the two-process rehearsal of ShardedRenderer on a single GPU (gloo backend, both ranks on
+device 0).  Launched by tests/test_gpu_sharded_renderer.py; rank 0 saves the gathered frame."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import cudaraytracer_amd as crt  # noqa: E402
+from cudaraytracer_amd.parallel import ShardedRenderer  # noqa: E402
+
+
+def main():
+    out, w, h, bounces, mode = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    sr = ShardedRenderer(dist, torch, rank, world, 0)
+    prims = np.concatenate([crt.scene_teapot(with_sphere=True), crt.scene_soup(5000, seed=6)]) if rank == 0 else None
+    sr.broadcast_scene(prims, crt.default_lights() if rank == 0 else None, mode)
+    cam, tgt = crt.default_camera()
+    p = crt.default_params(width=w, height=h, bounces=bounces)
+    for _ in range(2):                                   # twice: buffers and tile lists are reused
+        frame = sr.render(cam, tgt, p)
+    if rank == 0:
+        np.save(out, frame.cpu().numpy().reshape(h, w, 3))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
