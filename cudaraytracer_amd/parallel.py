@@ -153,8 +153,9 @@ class ShardedRenderer:
                     self.gathered[r].copy_(got[r])
         else:
             self.dist.gather(self.packed, self.gathered, dst=0)
+        # every rank waits for its part of the gather: the next frame packs into the same buffer on another stream
+        self.torch.cuda.synchronize(self.dev)
         if self.rank == 0:
-            self.torch.cuda.synchronize(self.dev)
             for r in range(1, self.world):
                 self.ctx.tiles_unpack(params, r, self.gathered[r].data_ptr(), self.frame.data_ptr())
             self.ctx.sync()
