@@ -817,8 +817,8 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
         if (getenv("CRT_DEBUG_SCHED"))      /* wave scheduling statistics of k_trace8 */
             for (int m = 0; m < 2; m++) {
                 const unsigned long long* q = t + 16 * m + 8;
-                fprintf(stderr, "[crt sched %s] node iterations %llu (%.1f lanes served), prim iterations %llu (%.1f lanes served), active lanes per iteration %.1f\n",
-                        m ? "shadow" : "nearest", q[0], q[0] ? (double)q[1] / q[0] : 0., q[2], q[2] ? (double)q[3] / q[2] : 0., (q[0] + q[2]) ? (double)q[4] / (q[0] + q[2]) : 0.);
+                fprintf(stderr, "[crt sched %s] node iterations %llu (%.1f lanes served), prim iterations %llu (%.1f lanes served), active lanes per iteration %.1f, visits with no child hit %llu of %llu\n",
+                        m ? "shadow" : "nearest", q[0], q[0] ? (double)q[1] / q[0] : 0., q[2], q[2] ? (double)q[3] / q[2] : 0., (q[0] + q[2]) ? (double)q[4] / (q[0] + q[2]) : 0., q[5], t[16 * m + 3]);
             }
         st.box_tests = t[0]; st.tri_tests = t[1]; st.sph_tests = t[2]; st.node_visits = t[3];
         st.box_tests_shadow = t[16]; st.tri_tests_shadow = t[17]; st.sph_tests_shadow = t[18]; st.node_visits_shadow = t[19];

@@ -453,7 +453,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
     int found = 0;
     int lightj = 0;
     unsigned long long nbox = 0, ntri = 0, nsph = 0, nvis = 0;
-    unsigned long long sch[5] = {0, 0, 0, 0, 0};
+    unsigned long long sch[5] = {0, 0, 0, 0, 0}, nzero = 0;
 
     for (;;) {
         /* ---- refill, first half: when enough lanes are idle, take rays off the queue and ISSUE their
@@ -571,7 +571,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
 #undef PAIR23
                         const uint32_t vmask = h1.x >> 24, imask = em >> 24;
                         raw &= vmask;                       /* an empty slot can pass the padded test of a degenerate node */
-                        if (COUNT) { nbox += (unsigned long long)__popc(vmask); nvis++; }
+                        if (COUNT) { nbox += (unsigned long long)__popc(vmask); nvis++; if (raw == 0u) nzero++; }
                         gbase = h1.x & 0xffffffu;
                         gmask = (imask << 8) | (uint32_t)s_perm[R][raw & imask];
                         plm = h1.y | ((raw & ~imask) << 24);
@@ -673,6 +673,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
         atomicAdd(&A.counters[2], nsph);
         atomicAdd(&A.counters[3], nvis);
         if (lane == 0) for (int i = 0; i < 5; i++) atomicAdd(&A.counters[8 + i], sch[i]);
+        atomicAdd(&A.counters[13], nzero);
     }
 }
 
