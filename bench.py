@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric on its own workload: Mrays/s (primary + shadow + reflection
 traversals actually issued) and frame ms on the synthetic 1M-triangle soup at 3840x2160, bounces=3
-(configs[3]); tiles of the same frame sharded over N GPUs (strong scaling, configs[4]'s mechanism).
+(configs[3]); on N GPUs the frame grows with N at a fixed pixel count per GPU and its tiles are sharded over the
+ranks (weak scaling, configs[4]'s mechanism; --strong shards the same 4K frame instead).
 
 A "step" is one frame of the hot path: gen_primary -> [trace -> shade -> shadow trace -> resolve] x
 bounces -> convert, with the scene + BVH already resident in HBM and the frame left in HBM
@@ -90,6 +91,7 @@ def main():
     ap.add_argument("--spp", type=int, default=1)
     ap.add_argument("--bvh", type=int, default=0, help="0 wide SAH built on the host (default), 1 reference topology, 2 wide LBVH built on the device")
     ap.add_argument("--sort-rays", type=int, default=0, help="1: visit secondary rays in Morton order of their origin cell")
+    ap.add_argument("--strong", action="store_true", help="N > 1: shard the SAME --width x --height frame (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--out-bmp", default=None)
@@ -113,7 +115,17 @@ def main():
 
     cam, tgt = crt.default_camera()
     lights = crt.default_lights()
-    params = crt.default_params(width=a.width, height=a.height, bounces=a.bounces, spp=a.spp, rank=rank, nranks=world,
+    # N > 1: WEAK scaling -- the pixels per GPU stay those of the --width x --height frame and the frame grows with N
+    # (3840x2160, 7680x2160, 7680x4320, 15360x4320 for N = 1, 2, 4, 8; configs[4] is the N = 4 frame size); its tiles
+    # are sharded over the ranks and gathered to rank 0 every frame
+    fw, fh = a.width, a.height
+    if world > 1 and not a.strong:
+        k = world.bit_length() - 1 if world & (world - 1) == 0 else None
+        if k is None:
+            fw = a.width * world
+        else:
+            fw, fh = a.width << ((k + 1) // 2), a.height << (k // 2)
+    params = crt.default_params(width=fw, height=fh, bounces=a.bounces, spp=a.spp, rank=rank, nranks=world,
                                 sort_rays=a.sort_rays)
     prims = crt.scene_soup(a.tris, seed=1) if (rank == 0 or world == 1) else None
     log(f"scene generated: {a.tris} triangles")
@@ -219,12 +231,12 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_step, 4),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "strong" if a.strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"configs[3]: synthetic {a.tris}-triangle random soup (seed 1), {a.width}x{a.height}, "
+                "workload": f"configs[3]: synthetic {a.tris}-triangle random soup (seed 1), {fw}x{fh} ({a.width * a.height} pixels per GPU), "
                             f"bounces={a.bounces} (primary + {a.bounces - 1} reflections), 2 directional lights, "
                             f"spp={a.spp}; frame tiles 32x32 sharded over {world} GPU(s)" + ("; sorted secondary rays" if a.sort_rays else ""),
                 "bvh": {0: "wide8-sah-compressed", 1: "reference-topology", 2: "wide8-lbvh-device-built"}[a.bvh],
