@@ -178,8 +178,8 @@ def main():
     fence()
     log("timed steps")
     t0 = time.perf_counter()
-    acc = {"ms_trace_nearest": 0.0, "ms_trace_shadow": 0.0, "ms_total": 0.0, "ms_shade": 0.0, "ms_other": 0.0,
-           "launches_trace_nearest": 0, "launches_trace_shadow": 0}
+    acc = {"ms_trace": 0.0, "ms_trace_nearest": 0.0, "ms_trace_shadow": 0.0, "ms_trace_mixed": 0.0, "ms_total": 0.0, "ms_shade": 0.0,
+           "ms_other": 0.0, "launches_trace_nearest": 0, "launches_trace_shadow": 0, "launches_trace_mixed": 0}
     for _ in range(a.steps):
         step()
         st = ctx.stats()
@@ -202,18 +202,23 @@ def main():
 
     if rank == 0:
         ms_step = elapsed / a.steps * 1e3
-        # roofline of the dominant kernel, k_trace<NEAREST>, on rank 0's launches
+        # roofline of the dominant kernel on rank 0's launches.  Wide BVH: k_trace8 serves the shadow rays of a bounce
+        # and the nearest-hit rays of the next in one launch, so the kernel's figure covers all its launches of a
+        # frame (bounces + 1) and all their rays; reference topology: k_trace<NEAREST>'s own launches.
         n_near = cst["rays_primary"] + cst["rays_reflect"]
         bytes_near = algorithmic_bytes(n_near, cst["box_tests"], cst["tri_tests"], cst["sph_tests"])
         bytes_shadow = algorithmic_bytes(cst["rays_shadow"], cst["box_tests_shadow"], cst["tri_tests_shadow"],
                                          cst["sph_tests_shadow"])
-        launches = max(1, acc["launches_trace_nearest"])
-        avg_ms = acc["ms_trace_nearest"] / launches
-        per_launch_bytes = bytes_near / max(1, cst["launches_trace_nearest"])
+        if a.bvh != 1:
+            launches = max(1, acc["launches_trace_nearest"] + acc["launches_trace_shadow"] + acc["launches_trace_mixed"])
+            avg_ms = acc["ms_trace"] / launches
+            per_launch_bytes = (bytes_near + bytes_shadow) / max(1, cst["launches_trace_nearest"] + cst["launches_trace_shadow"]
+                                                                  + cst["launches_trace_mixed"])
+        else:
+            launches = max(1, acc["launches_trace_nearest"])
+            avg_ms = acc["ms_trace_nearest"] / launches
+            per_launch_bytes = bytes_near / max(1, cst["launches_trace_nearest"])
         achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        sh_launches = max(1, acc["launches_trace_shadow"])
-        sh_avg_ms = acc["ms_trace_shadow"] / sh_launches
-        sh_achieved = (bytes_shadow / max(1, cst["launches_trace_shadow"])) / (sh_avg_ms * 1e-3) / 1e9 if sh_avg_ms > 0 else 0.0
         # HBM-side bytes per launch of the same kernel from the committed PMC passes (rocprofv3 cannot be
         # nested inside this process): only quoted for the default workload those passes measured
         traffic = None
@@ -242,29 +247,30 @@ def main():
                 "bvh": {0: "wide8-sah-compressed", 1: "reference-topology", 2: "wide8-lbvh-device-built"}[a.bvh],
                 "rays_per_frame": {"primary": int(rays[0]), "shadow": int(rays[1]), "reflect": int(rays[2])},
                 "frame_ms_device_rank0": round(acc["ms_total"] / a.steps, 4),
-                "frame_ms_split_rank0": {"trace_nearest": round(acc["ms_trace_nearest"] / a.steps, 4),
-                                         "trace_shadow": round(acc["ms_trace_shadow"] / a.steps, 4),
+                "frame_ms_split_rank0": {"trace": round(acc["ms_trace"] / a.steps, 4),
+                                         "trace_primary_only": round(acc["ms_trace_nearest"] / a.steps, 4),
+                                         "trace_shadow_plus_next_bounce": round(acc["ms_trace_mixed"] / a.steps, 4),
+                                         "trace_last_shadow_only": round(acc["ms_trace_shadow"] / a.steps, 4),
                                          "shade_resolve": round(acc["ms_shade"] / a.steps, 4),
                                          "gen_convert": round(acc["ms_other"] / a.steps, 4)},
                 "bvh_nodes": cst["nodes"], "bvh_depth": cst["depth"], "scene_bytes": cst["scene_bytes"],
                 "bvh_build_host_ms": round(cst["ms_build_host"], 1), "bvh_build_device_ms": round(cst["ms_build_device"], 2),
             },
             "roofline": {
-                "kernel": "k_trace8<NEAREST>" if a.bvh != 1 else "k_trace<NEAREST>", "bound": "hbm",
+                "kernel": "k_trace8" if a.bvh != 1 else "k_trace<NEAREST>", "bound": "hbm",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(per_launch_bytes), "avg_launch_ms": round(avg_ms, 4),
-                "launches_timed": acc["launches_trace_nearest"],
+                "launches_timed": launches,
                 "per_ray": {"node_visits": round(cst["node_visits"] / max(1, n_near), 2),
                             "box_tests": round(cst["box_tests"] / max(1, n_near), 2),
                             "tri_tests": round(cst["tri_tests"] / max(1, n_near), 2),
                             "bytes": round(bytes_near / max(1, n_near), 1)},
-                "shadow_kernel": {"kernel": "k_trace8<SHADOW>" if a.bvh != 1 else "k_trace<SHADOW>", "achieved": round(sh_achieved, 2),
-                                  "frac": round(sh_achieved / HBM_PEAK_GBS, 5), "avg_launch_ms": round(sh_avg_ms, 4),
-                                  "per_ray_node_visits": round(cst["node_visits_shadow"] / max(1, cst["rays_shadow"]), 2),
-                                  "per_ray_box_tests": round(cst["box_tests_shadow"] / max(1, cst["rays_shadow"]), 2),
-                                  "per_ray_tri_tests": round(cst["tri_tests_shadow"] / max(1, cst["rays_shadow"]), 2)},
+                "per_shadow_ray": {"node_visits": round(cst["node_visits_shadow"] / max(1, cst["rays_shadow"]), 2),
+                                   "box_tests": round(cst["box_tests_shadow"] / max(1, cst["rays_shadow"]), 2),
+                                   "tri_tests": round(cst["tri_tests_shadow"] / max(1, cst["rays_shadow"]), 2),
+                                   "bytes": round(bytes_shadow / max(1, cst["rays_shadow"]), 1)},
             },
         }
         if world == 1:

@@ -54,7 +54,8 @@ class Stats(C.Structure):
                 ("launches_trace_nearest", C.c_int32), ("launches_trace_shadow", C.c_int32),
                 ("nodes", C.c_int32), ("prims", C.c_int32), ("depth", C.c_int32), ("leaves", C.c_int32),
                 ("ms_build_host", C.c_double), ("ms_refit", C.c_double), ("scene_bytes", C.c_uint64),
-                ("node_visits", C.c_uint64), ("node_visits_shadow", C.c_uint64), ("ms_build_device", C.c_double)]
+                ("node_visits", C.c_uint64), ("node_visits_shadow", C.c_uint64), ("ms_build_device", C.c_double),
+                ("ms_trace_mixed", C.c_double), ("launches_trace_mixed", C.c_int32), ("pad_", C.c_int32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

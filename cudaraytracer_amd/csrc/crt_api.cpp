@@ -69,7 +69,8 @@ struct crt_ctx {
     uint32_t* d_tiles = nullptr; size_t tiles_cap = 0; std::vector<uint32_t> tiles; crt_params tiles_for{}; int64_t owned_pixels = 0;
     std::vector<uint32_t*> tl_ids; std::vector<int> tl_n; crt_params tl_key{};      /* per-rank tile lists for pack/unpack */
     uint32_t* d_ctr = nullptr; size_t ctr_cap = 0; std::vector<uint32_t> h_ctr;
-    uint32_t *d_sortkeys = nullptr, *d_sortperm = nullptr, *d_sorthist = nullptr; size_t sort_cap = 0;
+    uint32_t *d_sortkeys = nullptr, *d_sortperm = nullptr, *d_sorthist = nullptr; size_t sort_cap = 0;     /* shadow queue */
+    uint32_t *d_sortkeys2 = nullptr, *d_sortperm2 = nullptr;                                                 /* reflection queue */
     void* d_lbvh = nullptr; size_t lbvh_cap = 0;                 /* scratch of the device builder */
     Node8* d_lbvh_nodes = nullptr; size_t lbvh_nodes_cap = 0;    /* its output before the blob is laid out */
     uint32_t* d_lbvh_s2s = nullptr; size_t lbvh_s2s_cap = 0;
@@ -204,7 +205,7 @@ hipEvent_t next_event(crt_ctx* c) {
     if (c->evused == c->evpool.size()) { hipEvent_t e; hipEventCreate(&e); c->evpool.push_back(e); }
     return c->evpool[c->evused++];
 }
-enum { EV_START = 0, EV_GEN, EV_TRACE_N, EV_SHADE, EV_TRACE_S, EV_RESOLVE, EV_CONVERT, EV_SORT };
+enum { EV_START = 0, EV_GEN, EV_TRACE_N, EV_SHADE, EV_TRACE_S, EV_RESOLVE, EV_CONVERT, EV_SORT, EV_TRACE_M };
 void mark(crt_ctx* c, int kind) {
     hipEvent_t e = next_event(c);
     hipEventRecord(e, c->stream);
@@ -331,7 +332,7 @@ void crt_destroy(crt_ctx* c) {
     void* ptrs[] = {c->d_blob, c->d_prims, c->d_matid, c->d_arrive, c->rayO[0], c->rayO[1], c->rayD[0], c->rayD[1],
                     c->coef[0], c->coef[1], c->pix[0], c->pix[1], c->hitSlot, c->hitT, c->rc, c->contrib, c->shO, c->shD,
                     c->accum, c->sum, c->shflag, c->d_bgr, c->cap_ids, c->cap_ts, c->d_tiles, c->d_ctr, c->d_status,
-                    c->d_testctr, c->d_ovf, c->d_sortkeys, c->d_sortperm, c->d_sorthist,
+                    c->d_testctr, c->d_ovf, c->d_sortkeys, c->d_sortperm, c->d_sorthist, c->d_sortkeys2, c->d_sortperm2,
                     c->d_lbvh, c->d_lbvh_nodes, c->d_lbvh_s2s};
     for (void* p : ptrs) if (p) hipFree(p);
     for (uint32_t* q : c->tl_ids) if (q) hipFree(q);
@@ -705,6 +706,8 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
         if (need > c->sort_cap || !c->d_sortkeys) {
             if ((rc = realloc_exact(c, c->d_sortkeys, need))) return rc;
             if ((rc = realloc_exact(c, c->d_sortperm, need))) return rc;
+            if ((rc = realloc_exact(c, c->d_sortkeys2, c->cap))) return rc;
+            if ((rc = realloc_exact(c, c->d_sortperm2, c->cap))) return rc;
             if (!c->d_sorthist && (rc = realloc_exact(c, c->d_sorthist, (size_t)kSortBins + 1))) return rc;
             c->sort_cap = need;
         }
@@ -736,36 +739,60 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
         bind(cur);
         launch_gen_primary(fp, fb, ctr + 0, c->stream);
         mark(c, EV_GEN);
+        const float* d_root_box = (const float*)((const char*)c->d_blob + offsetof(BlobHeader, root_box));
+        const bool wide = c->hdr.mode == CRT_BVH_WIDE;
+        auto common = [&](TraceArgs& t, int launch) {
+            t.sv = sv; t.next = ctr + kCtrFetch0 + launch * 8 * kFetchStride;
+            t.hitSlot = c->hitSlot; t.hitT = c->hitT; t.shflag = c->shflag; t.scene_abs = c->scene_abs;
+            t.ovf = c->d_ovf; t.ovf_depth = c->ovf_depth; t.counters = c->d_testctr; t.status = c->d_status;
+        };
         for (int b = 0; b < p->bounces; b++) {
             fp.bounce = b;
             bind(cur);
-            TraceArgs ta{};
-            ta.sv = sv; ta.rayO = fb.rayO; ta.rayD = fb.rayD; ta.count = ctr + b; ta.next = ctr + kCtrFetch0 + (2 * b) * 8 * kFetchStride;
-            ta.hitSlot = c->hitSlot; ta.hitT = c->hitT; ta.shflag = nullptr; ta.scene_abs = c->scene_abs;
-            const float* d_root_box = (const float*)((const char*)c->d_blob + offsetof(BlobHeader, root_box));
-            const bool wide = c->hdr.mode == CRT_BVH_WIDE;
-            if (p->sort_rays && wide && b > 0) {        /* reflection rays: visit them by origin cell (primary rays are coherent already) */
-                launch_sort_rays(fb.rayO, ctr + b, (uint32_t)c->cap, d_root_box, c->d_sortkeys, c->d_sorthist, c->d_sortperm, c->stream);
-                ta.perm = c->d_sortperm;
-                mark(c, EV_SORT);
+            if (!wide || b == 0) {
+                /* nearest hits of this bounce: the wide path has traced them already, together with the previous
+                 * bounce's shadow rays, except for the primary rays */
+                TraceArgs ta{};
+                common(ta, 2 * b);
+                ta.rayO = fb.rayO; ta.rayD = fb.rayD; ta.count = ctr + b;
+                launch_trace(ta, c->lights, TRACE_NEAREST, c->counting, wide, c->grid_blocks, c->stream);
+                mark(c, EV_TRACE_N);
             }
-            ta.ovf = c->d_ovf; ta.ovf_depth = c->ovf_depth; ta.counters = c->d_testctr; ta.status = c->d_status;
-            launch_trace(ta, c->lights, TRACE_NEAREST, c->counting, c->hdr.mode == CRT_BVH_WIDE, c->grid_blocks, c->stream);
-            mark(c, EV_TRACE_N);
             launch_shade(fp, fb, sv, c->lights, ctr + b, ctr + b + 1, ctr + 16 + b, c->stream);
             mark(c, EV_SHADE);
-            if (c->lights.n > 0) {
-                TraceArgs ts = ta;
-                ts.rayO = c->shO; ts.rayD = c->shD; ts.count = ctr + 16 + b; ts.next = ctr + kCtrFetch0 + (2 * b + 1) * 8 * kFetchStride;
-                ts.hitSlot = nullptr; ts.hitT = nullptr; ts.shflag = c->shflag; ts.counters = c->d_testctr + 16;
-                ts.perm = nullptr;
-                if (p->sort_rays && wide) {
-                    launch_sort_rays(c->shO, ctr + 16 + b, (uint32_t)(c->cap * (size_t)c->lights.n), d_root_box, c->d_sortkeys, c->d_sorthist,
-                                     c->d_sortperm, c->stream);
-                    ts.perm = c->d_sortperm;
-                    mark(c, EV_SORT);
+            if (wide) {
+                /* ONE launch for the shadow rays of this bounce and the nearest-hit rays of the next: they are
+                 * independent, and every persistent launch ends in a ~0.25 ms tail of its longest rays */
+                TraceArgs tm{};
+                common(tm, 2 * b + 1);
+                const bool has_sh = c->lights.n > 0, has_nx = b + 1 < p->bounces;
+                if (has_sh) {
+                    tm.shO = c->shO; tm.shD = c->shD; tm.shcount = ctr + 16 + b;
+                    if (p->sort_rays) {
+                        launch_sort_rays(c->shO, ctr + 16 + b, (uint32_t)(c->cap * (size_t)c->lights.n), d_root_box, c->d_sortkeys, c->d_sorthist,
+                                         c->d_sortperm, c->stream);
+                        tm.shperm = c->d_sortperm;
+                        mark(c, EV_SORT);
+                    }
                 }
-                launch_trace(ts, c->lights, TRACE_SHADOW, c->counting, c->hdr.mode == CRT_BVH_WIDE, c->grid_blocks, c->stream);
+                if (has_nx) {
+                    tm.rayO = fb.nrayO; tm.rayD = fb.nrayD; tm.count = ctr + b + 1;
+                    if (p->sort_rays) {      /* reflection rays: visit them by origin cell (primary rays are coherent already) */
+                        launch_sort_rays(fb.nrayO, ctr + b + 1, (uint32_t)c->cap, d_root_box, c->d_sortkeys2, c->d_sorthist, c->d_sortperm2, c->stream);
+                        tm.perm = c->d_sortperm2;
+                        mark(c, EV_SORT);
+                    }
+                }
+                if (has_sh || has_nx) {
+                    launch_trace(tm, c->lights, TRACE_NEAREST, c->counting, true, c->grid_blocks, c->stream);
+                    mark(c, has_sh && has_nx ? EV_TRACE_M : (has_sh ? EV_TRACE_S : EV_TRACE_N));
+                }
+            } else if (c->lights.n > 0) {
+                TraceArgs ts{};
+                common(ts, 2 * b + 1);
+                ts.rayO = c->shO; ts.rayD = c->shD; ts.count = ctr + 16 + b;
+                ts.hitSlot = nullptr; ts.hitT = nullptr; ts.counters = c->d_testctr + 16;
+                launch_trace(ts, c->lights, TRACE_SHADOW, c->counting, false, c->grid_blocks, c->stream);
                 mark(c, EV_TRACE_S);
             }
             launch_resolve(fb, c->lights, ctr + b, c->stream);
@@ -796,14 +823,15 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
         for (int b = 1; b < p->bounces; b++) st.rays_reflect += h[b];
         for (int b = 0; b < p->bounces; b++) st.rays_shadow += h[16 + b];
     }
-    st.ms_trace = st.ms_shade = st.ms_other = st.ms_trace_nearest = st.ms_trace_shadow = 0;
-    st.launches_trace_nearest = st.launches_trace_shadow = 0;
+    st.ms_trace = st.ms_shade = st.ms_other = st.ms_trace_nearest = st.ms_trace_shadow = st.ms_trace_mixed = 0;
+    st.launches_trace_nearest = st.launches_trace_shadow = st.launches_trace_mixed = 0;
     for (size_t i = 1; i < c->evlog.size(); i++) {
         float ms = 0;
         hipEventElapsedTime(&ms, c->evpool[c->evlog[i - 1].second], c->evpool[c->evlog[i].second]);
         switch (c->evlog[i].first) {
             case EV_TRACE_N: st.ms_trace += ms; st.ms_trace_nearest += ms; st.launches_trace_nearest++; break;
             case EV_TRACE_S: st.ms_trace += ms; st.ms_trace_shadow += ms; st.launches_trace_shadow++; break;
+            case EV_TRACE_M: st.ms_trace += ms; st.ms_trace_mixed += ms; st.launches_trace_mixed++; break;
             case EV_SHADE: case EV_RESOLVE: st.ms_shade += ms; break;
             default: st.ms_other += ms;
         }
@@ -815,11 +843,12 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
         unsigned long long t[32];
         HIPCHECK(c, hipMemcpy(t, c->d_testctr, sizeof t, hipMemcpyDeviceToHost));
         if (getenv("CRT_DEBUG_SCHED"))      /* wave scheduling statistics of k_trace8 */
-            for (int m = 0; m < 2; m++) {
-                const unsigned long long* q = t + 16 * m + 8;
-                fprintf(stderr, "[crt sched %s] node iterations %llu (%.1f lanes served), prim iterations %llu (%.1f lanes served), active lanes per iteration %.1f, visits with no child hit %llu of %llu\n",
-                        m ? "shadow" : "nearest", q[0], q[0] ? (double)q[1] / q[0] : 0., q[2], q[2] ? (double)q[3] / q[2] : 0., (q[0] + q[2]) ? (double)q[4] / (q[0] + q[2]) : 0., q[5], t[16 * m + 3]);
-            }
+        {
+            const unsigned long long* q = t + 8;
+            fprintf(stderr, "[crt sched] node iterations %llu (%.1f lanes served), prim iterations %llu (%.1f lanes served), active lanes per iteration %.1f, "
+                            "visits with no child hit %llu of %llu\n",
+                    q[0], q[0] ? (double)q[1] / q[0] : 0., q[2], q[2] ? (double)q[3] / q[2] : 0., (q[0] + q[2]) ? (double)q[4] / (q[0] + q[2]) : 0., q[5], t[3] + t[19]);
+        }
         st.box_tests = t[0]; st.tri_tests = t[1]; st.sph_tests = t[2]; st.node_visits = t[3];
         st.box_tests_shadow = t[16]; st.tri_tests_shadow = t[17]; st.sph_tests_shadow = t[18]; st.node_visits_shadow = t[19];
     }
@@ -879,6 +908,10 @@ static int trace_hook(crt_ctx* c, const float* org_dir, int n, int32_t* prim_out
         ta.hitSlot = d_slot; ta.hitT = d_t; ta.shflag = d_flag; ta.scene_abs = c->scene_abs;
         ta.ovf = c->d_ovf; ta.ovf_depth = c->ovf_depth; ta.counters = c->d_testctr; ta.status = c->d_status;
         if (c->counting) TH(hipMemsetAsync(c->d_testctr, 0, 32 * sizeof(unsigned long long), c->stream));
+        if (shadow_out && c->hdr.mode == CRT_BVH_WIDE) {      /* k_trace8 takes shadow rays in its second queue */
+            ta.shO = d_o; ta.shD = d_d; ta.shcount = d_cnt;
+            ta.rayO = nullptr; ta.rayD = nullptr; ta.count = nullptr;
+        }
         LightsParam dummy{}; dummy.n = 1;          /* light 0 directional: the Ray.cu:650-656 predicate */
         hipEvent_t e0 = next_event(c), e1 = next_event(c);
         c->evused -= 2;
@@ -895,9 +928,10 @@ static int trace_hook(crt_ctx* c, const float* org_dir, int n, int32_t* prim_out
         TH(hipStreamSynchronize(c->stream));
         { float ms = 0; hipEventElapsedTime(&ms, e0, e1); c->stats.ms_trace = ms; }     /* the traversal launch alone */
         if (c->counting) {
-            unsigned long long t[4];
+            unsigned long long t[32];
             TH(hipMemcpy(t, c->d_testctr, sizeof t, hipMemcpyDeviceToHost));
-            c->stats.box_tests = t[0]; c->stats.tri_tests = t[1]; c->stats.sph_tests = t[2]; c->stats.node_visits = t[3];
+            const unsigned long long* q = (shadow_out && c->hdr.mode == CRT_BVH_WIDE) ? t + 16 : t;
+            c->stats.box_tests = q[0]; c->stats.tri_tests = q[1]; c->stats.sph_tests = q[2]; c->stats.node_visits = q[3];
         }
     }
 done:

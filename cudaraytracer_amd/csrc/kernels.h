@@ -90,8 +90,11 @@ enum TraceMode { TRACE_NEAREST = 0, TRACE_SHADOW = 1 };
 struct TraceArgs {
     SceneView sv;
     const float4* rayO; const float4* rayD;
-    const uint32_t* count;       /* number of rays (device) */
+    const uint32_t* count;       /* number of rays (device); k_trace8: the nearest-hit queue, null = none */
     const uint32_t* perm;        /* optional visiting order (crt_params.sort_rays): queue position -> ray, or null */
+    const float4* shO; const float4* shD;    /* k_trace8 only: the shadow queue served by the same launch, */
+    const uint32_t* shcount;                 /* null = none (k_trace takes its one queue in rayO/rayD/count) */
+    const uint32_t* shperm;
     uint32_t* next;              /* 8 fetch counters, kFetchStride words apart (device, zeroed) */
     int32_t* hitSlot; float* hitT;           /* NEAREST outputs */
     uint8_t* shflag;                         /* SHADOW output, indexed by the target in rayO.w */

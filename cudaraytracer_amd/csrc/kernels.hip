@@ -416,7 +416,7 @@ CRT_DEV void slab8(uint32_t& raw, uint32_t wnx, uint32_t wfx, uint32_t wny, uint
 #else
 #define CRT_TRACE8_BOUNDS __launch_bounds__(kTraceBlock)
 #endif
-template <int MODE, bool COUNT>
+template <bool COUNT>
 __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
     __shared__ uint2 s_stack[kStackDepth8][kTraceBlock];
     __shared__ uint8_t s_perm[8][256];     /* s_perm[R][m]: bit k of m moved to bit k ^ R */
@@ -429,7 +429,14 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
         s_perm[R_][m] = (uint8_t)y;
     }
     __syncthreads();
-    const uint32_t total = *A.count;
+    /* one launch serves TWO independent queues: the shadow rays of a bounce and the nearest-hit rays of the
+     * next one (either may be absent).  A launch of even a thousand rays lasts 0.23 ms -- a ray is ~100
+     * dependent node visits -- so two launches per bounce meant two such tails.  Virtual queue positions
+     * [0, ns64) are shadow rays, [ns64, total) nearest-hit rays; ns64 is a multiple of the chunk size, so a
+     * chunk never straddles the two.  Bit 31 of `ray` marks a lane that carries a shadow ray. */
+    const uint32_t total_s = A.shcount ? *A.shcount : 0u, total_n = A.count ? *A.count : 0u;
+    const uint32_t ns64 = (total_s + (uint32_t)kFetchChunk - 1u) / (uint32_t)kFetchChunk * (uint32_t)kFetchChunk;
+    const uint32_t total = ns64 + total_n;
     const uint32_t gthread = blockIdx.x * kTraceBlock + tid;
     uint2* ovf = reinterpret_cast<uint2*>(A.ovf) + (size_t)gthread * (size_t)(A.ovf_depth > 0 ? A.ovf_depth : 0);
     const char* qbase = reinterpret_cast<const char*>(A.sv.qnodes);
@@ -452,7 +459,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
     int sp = 0;
     int found = 0;
     int lightj = 0;
-    unsigned long long nbox = 0, ntri = 0, nsph = 0, nvis = 0;
+    unsigned long long nbox[2] = {0, 0}, ntri[2] = {0, 0}, nsph[2] = {0, 0}, nvis[2] = {0, 0};      /* [0] nearest-hit rays, [1] shadow rays */
     unsigned long long sch[5] = {0, 0, 0, 0, 0}, nzero = 0;
 
     for (;;) {
@@ -460,7 +467,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
          *      loads; the set-up runs after this iteration's traversal step, whose own node / primitive
          *      loads return later (loads return in order), so the refill costs the wave no extra stall ---- */
         bool pend = false;
-        float3 pro3; float4 pro4, prd;      /* read only by the lanes that set pend; `ray` carries the queue index */
+        float4 pro4, prd;      /* read only by the lanes that set pend; `ray` carries the queue index */
         if (!exhausted) {
             const unsigned long long idle = __ballot(!active);
             const int nidle = __popcll(idle);
@@ -487,13 +494,18 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
                 if (!exhausted) {
                     const uint32_t idx = cnext + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                     const uint32_t take = (uint32_t)nidle < cend - cnext ? (uint32_t)nidle : cend - cnext;
-                    const bool mine = !active && idx < cend;
+                    const bool sh = cnext < ns64;          /* wave-uniform: the chunk lies in one queue */
+                    const bool mine = !active && idx < cend && (!sh || idx < total_s);
                     cnext += take;
                     if (mine) {          /* issue the loads only: they complete under the traversal step below */
-                        const uint32_t q = A.perm ? A.perm[idx] : idx;      /* sorted visiting order, if any */
-                        if (MODE == TRACE_SHADOW) pro4 = A.rayO[q];
-                        else pro3 = *reinterpret_cast<const float3*>(A.rayO + q);        /* .w is only used by shadow rays */
-                        prd = A.rayD[q]; ray = q; pend = true;
+                        if (sh) {
+                            const uint32_t q = A.shperm ? A.shperm[idx] : idx;      /* sorted visiting order, if any */
+                            pro4 = A.shO[q]; prd = A.shD[q]; ray = q | 0x80000000u;
+                        } else {
+                            const uint32_t q = A.perm ? A.perm[idx - ns64] : idx - ns64;
+                            pro4 = A.rayO[q]; prd = A.rayD[q]; ray = q;
+                        }
+                        pend = true;
                     }
                 }
             }
@@ -571,7 +583,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
 #undef PAIR23
                         const uint32_t vmask = h1.x >> 24, imask = em >> 24;
                         raw &= vmask;                       /* an empty slot can pass the padded test of a degenerate node */
-                        if (COUNT) { nbox += (unsigned long long)__popc(vmask); nvis++; if (raw == 0u) nzero++; }
+                        if (COUNT) { nbox[ray >> 31] += (unsigned long long)__popc(vmask); nvis[ray >> 31]++; if (raw == 0u) nzero++; }
                         gbase = h1.x & 0xffffffu;
                         gmask = (imask << 8) | (uint32_t)s_perm[R][raw & imask];
                         plm = h1.y | ((raw & ~imask) << 24);
@@ -592,10 +604,11 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
                     const GeomRec g = load_geom(A.sv.geom, p);
                     float t = 0.f, tsm;
                     bool hit;
-                    if (is_sphere(g)) { if (COUNT) nsph++; hit = sphere_test(g, o, d, t, tsm); }
-                    else { if (COUNT) ntri++; hit = tri_test(g, o, d, tbest, t); }
+                    const bool shray = (ray >> 31) != 0u;
+                    if (is_sphere(g)) { if (COUNT) nsph[shray]++; hit = sphere_test(g, o, d, t, tsm); }
+                    else { if (COUNT) ntri[shray]++; hit = tri_test(g, o, d, tbest, t); }
                     if (hit) {
-                        if (MODE == TRACE_NEAREST) {
+                        if (!shray) {
                             if (t < tbest || (t == tbest && best >= 0 && A.sv.rank[p] < A.sv.rank[best])) { tbest = t; best = (int)p; }
                         } else {
                             if (LP.l[lightj].point) {
@@ -610,7 +623,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
                 }
             }
             if (finish) {
-                if (MODE == TRACE_NEAREST) {
+                if (!(ray >> 31)) {
                     A.hitSlot[ray] = best;
                     A.hitT[ray] = tbest;
                 } else {
@@ -627,22 +640,23 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
                             shadowed = dtoLight > dtoLightIntersection;
                         }
                     } else shadowed = (found != 0);
-                    if (shadowed) A.shflag[ray] = 1;
+                    if (shadowed) A.shflag[ray & 0x7fffffffu] = 1;
                 }
                 active = false; lp = lend = 0; plm = 0;
             }
         }
         /* ---- refill, second half: ray set-up for the lanes whose loads were issued above ---- */
         if (pend) {
-            const float4 ro = MODE == TRACE_SHADOW ? pro4 : make_float4(pro3.x, pro3.y, pro3.z, 0.f), rd = prd;
-            const uint32_t idx = ray;
-            if (MODE == TRACE_NEAREST && __float_as_uint(rd.w) == 0xffffffffu) {
+            const float4 ro = pro4, rd = prd;
+            const bool shray = (ray >> 31) != 0u;
+            const uint32_t idx = ray & 0x7fffffffu;
+            if (!shray && __float_as_uint(rd.w) == 0xffffffffu) {
                 A.hitSlot[idx] = -3;
                 A.hitT[idx] = 0.f;
             } else {
                 ray = idx;
                 o = vec3(ro.x, ro.y, ro.z); d = vec3(rd.x, rd.y, rd.z);
-                if (MODE == TRACE_SHADOW) { ray = __float_as_uint(ro.w); lightj = (int)__float_as_uint(rd.w); }
+                if (shray) { ray = __float_as_uint(ro.w) | 0x80000000u; lightj = (int)__float_as_uint(rd.w); }
                 /* v_rcp_f32 (1 ulp) instead of an IEEE division: the box test only has to be
                  * conservative and the pad below is 1e4 times that error */
                 float rx = __builtin_amdgcn_rcpf(d.x), ry = __builtin_amdgcn_rcpf(d.y), rz = __builtin_amdgcn_rcpf(d.z);
@@ -668,10 +682,12 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
         if (exhausted && __ballot(active) == 0ull) break;
     }
     if (COUNT) {
-        atomicAdd(&A.counters[0], nbox);
-        atomicAdd(&A.counters[1], ntri);
-        atomicAdd(&A.counters[2], nsph);
-        atomicAdd(&A.counters[3], nvis);
+        for (int m = 0; m < 2; m++) {          /* nearest-hit counters at [0..3], shadow counters at [16..19] */
+            atomicAdd(&A.counters[16 * m + 0], nbox[m]);
+            atomicAdd(&A.counters[16 * m + 1], ntri[m]);
+            atomicAdd(&A.counters[16 * m + 2], nsph[m]);
+            atomicAdd(&A.counters[16 * m + 3], nvis[m]);
+        }
         if (lane == 0) for (int i = 0; i < 5; i++) atomicAdd(&A.counters[8 + i], sch[i]);
         atomicAdd(&A.counters[13], nzero);
     }
@@ -683,7 +699,7 @@ int trace_grid_blocks(int device) {
     /* persistent grid = what is resident at once: limited by the LDS stack per block and by the
      * kernel's VGPR allocation; ask the runtime for the tighter of the two */
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace8<TRACE_NEAREST, false>, kTraceBlock, 0) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace8<false>, kTraceBlock, 0) != hipSuccess || per_cu < 1)
         per_cu = 4;
     if (per_cu > 8) per_cu = 8;
     return p.multiProcessorCount * per_cu;
@@ -691,14 +707,9 @@ int trace_grid_blocks(int device) {
 
 void launch_trace(const TraceArgs& a, const LightsParam& lights, int mode, bool counting, bool wide, int blocks, hipStream_t s) {
     dim3 g(blocks), b(kTraceBlock);
-    if (wide) {
-        if (mode == TRACE_NEAREST) {
-            if (counting) hipLaunchKernelGGL((k_trace8<TRACE_NEAREST, true>), g, b, 0, s, a, lights);
-            else hipLaunchKernelGGL((k_trace8<TRACE_NEAREST, false>), g, b, 0, s, a, lights);
-        } else {
-            if (counting) hipLaunchKernelGGL((k_trace8<TRACE_SHADOW, true>), g, b, 0, s, a, lights);
-            else hipLaunchKernelGGL((k_trace8<TRACE_SHADOW, false>), g, b, 0, s, a, lights);
-        }
+    if (wide) {          /* k_trace8 serves both of its queues in one launch; `mode` is not used */
+        if (counting) hipLaunchKernelGGL((k_trace8<true>), g, b, 0, s, a, lights);
+        else hipLaunchKernelGGL((k_trace8<false>), g, b, 0, s, a, lights);
     } else {
         if (mode == TRACE_NEAREST) {
             if (counting) hipLaunchKernelGGL((k_trace<TRACE_NEAREST, true>), g, b, 0, s, a, lights);

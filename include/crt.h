@@ -91,6 +91,10 @@ typedef struct crt_stats {
     uint64_t scene_bytes;    /* packed scene + BVH bytes resident in HBM */
     uint64_t node_visits, node_visits_shadow;   /* counting only: BVH nodes visited (one visit tests all its children) */
     double ms_build_device;  /* wall time of the last CRT_BVH_WIDE_DEVICE build */
+    /* the wide path traces the shadow rays of a bounce and the nearest-hit rays of the next in ONE launch: those
+     * launches are counted here, the pure ones (primary rays; last bounce's shadow rays) in the fields above */
+    double ms_trace_mixed;
+    int32_t launches_trace_mixed, pad_;
 } crt_stats;
 
 typedef struct crt_ctx crt_ctx;
