@@ -72,7 +72,7 @@ def main():
     json.dump(out, open(dst + ".json", "w"), indent=1, sort_keys=True)
     # HBM-side traffic of the dominant kernel for bench.py's roofline.traffic (it cannot collect PMC itself)
     for k, e in out["kernels"].items():
-        if k.startswith("k_trace8<0, false") and "hbm_read_bytes_per_launch_raw" in e and "hbm_write_bytes_per_launch" in e:
+        if k.startswith("k_trace8<false") and "hbm_read_bytes_per_launch_raw" in e and "hbm_write_bytes_per_launch" in e:
             json.dump({"kernel": k, "fetch_size_kib_per_launch": e["pmc_per_launch_avg"]["FETCH_SIZE"],
                        "write_size_kib_per_launch": e["pmc_per_launch_avg"]["WRITE_SIZE"],
                        "hbm_bytes_per_launch": e["hbm_read_bytes_per_launch_x2_gfx950"] + e["hbm_write_bytes_per_launch"],
