@@ -124,3 +124,37 @@ def test_device_build_of_tiny_scenes(crt, n):
         assert np.array_equal(ts_g[ids_o >= 0], ts_o[ids_o >= 0])
     finally:
         ctx.close(); sc.close()
+
+
+@pytest.mark.parametrize("mode", [0, DEVICE])
+def test_deep_tree_uses_the_stack_overflow_rows(crt, mode):
+    """exponentially spaced spheres give a chain-like tree deeper than the 14 stack entries kept in LDS:
+    the per-lane overflow rows in HBM take the rest, results unchanged"""
+    n, base = 300, 1.08
+    prims = crt.scene_spheres(n, seed=1)
+    k = np.arange(n)
+    prims["position"][:, 0] = (base ** k).astype(np.float32)
+    prims["position"][:, 1] = 0; prims["position"][:, 2] = 0
+    prims["radius"] = (0.01 * base ** k).astype(np.float32)
+    ctx = crt.Context(0)
+    ctx.set_scene(prims); ctx.build(mode)
+    sc = orc.Scene(prims); sc.build()
+    try:
+        if mode == 0:
+            assert ctx.stats()["depth"] > 14
+        rng = np.random.default_rng(5)
+        m = 50000
+        o = np.zeros((m, 3), np.float32)
+        o[:, 0] = (base ** rng.uniform(0, n, m)).astype(np.float32)
+        o[:, 1:] = rng.normal(size=(m, 2)).astype(np.float32) * (0.02 * o[:, :1])
+        d = rng.normal(size=(m, 3)).astype(np.float32)
+        d[: m // 2] = [1, 0, 0]; d[m // 2: 3 * m // 4] = [-1, 0, 0]
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rays = np.ascontiguousarray(np.concatenate([o, d.astype(np.float32)], axis=1))
+        ids_o, ts_o = sc.trace(rays)
+        ids_g, ts_g = ctx.trace(rays)
+        assert (ids_o >= 0).sum() > 10000
+        assert np.array_equal(ids_g, ids_o)
+        assert np.array_equal(ts_g[ids_o >= 0], ts_o[ids_o >= 0])
+    finally:
+        ctx.close(); sc.close()
