@@ -169,6 +169,31 @@ def test_point_light_and_odd_size(crt, teapot):
         sc.stats(reset=True)
 
 
+def test_no_lights_and_eight_lights(crt, teapot):
+    """the light loop of Ray.cu:560 with numlights = 0 (ambient only, no shadow queue) and with CRT_MAX_LIGHTS lights"""
+    prims, ctx, sc = teapot
+    try:
+        none = np.zeros(0, crt.LIGHT_DTYPE)
+        ctx.set_lights(none)
+        g, o, p = render_pair(crt, ctx, sc, 300, 200, 3, none)
+        check_image(g, o, "no lights 300x200 bounces=3")
+        assert ctx.stats()["rays_shadow"] == 0
+        many = np.zeros(8, crt.LIGHT_DTYPE)
+        rng = np.random.default_rng(3)
+        for k in range(8):
+            many[k]["color"] = rng.uniform(.05, .3, 3)
+            many[k]["direction"] = rng.normal(size=3)
+            if k % 3 == 2:
+                many[k]["point"] = 1; many[k]["position"] = rng.uniform(-60, 60, 3)
+                many[k]["constantTerm"] = 0.25; many[k]["linearTerm"] = 0.003372407; many[k]["quadraticTerm"] = 0.000045492
+        ctx.set_lights(many)
+        g, o, p = render_pair(crt, ctx, sc, 300, 200, 2, many)
+        check_image(g, o, "eight lights 300x200 bounces=2", max_bad=4)
+    finally:
+        ctx.set_lights(crt.default_lights())
+        sc.stats(reset=True)
+
+
 def test_spheres_scene_and_refit(crt):
     """configs[2] at test size: moving spheres, refit every frame, rebuild every 20th."""
     prims = crt.scene_spheres(2048, seed=1)
