@@ -336,6 +336,7 @@ struct WideBuilder {
 int build_wide(const crt_prim* prims, int n, const RefTree* ref, HostBVH& out) {
     out.nodes.clear(); out.nodes8.clear(); out.mode = CRT_BVH_WIDE; out.depth = 0; out.leaves = 0;
     out.slot_to_scene.clear(); out.slot_to_scene.reserve(n);
+    if (ref && (int)ref->order.size() != n) return -1;   /* reference tree of another scene */
     if (ref) ranks_from(*ref, n, out.rank_of_scene);
     else { out.rank_of_scene.resize(n); for (int i = 0; i < n; i++) out.rank_of_scene[i] = (uint32_t)i; }
 
