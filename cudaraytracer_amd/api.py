@@ -42,7 +42,7 @@ class Camera(C.Structure):
 class Params(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("bounces", C.c_int32), ("spp", C.c_int32),
                 ("tile_w", C.c_int32), ("tile_h", C.c_int32), ("rank", C.c_int32), ("nranks", C.c_int32),
-                ("sort_rays", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("sort_rays", C.c_int32), ("area_samples", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 class Stats(C.Structure):
@@ -71,7 +71,7 @@ ABI_SYMBOLS = [
     "crt_blob_size", "crt_blob_device_ptr", "crt_blob_import_device",
     "crt_tile_owner", "crt_tiles_owned", "crt_tiles_pack", "crt_tiles_unpack",
     "crt_get_stats", "crt_sync",
-    "crt_load_obj", "crt_scene_teapot", "crt_scene_spheres", "crt_scene_soup", "crt_lights_default",
+    "crt_load_obj", "crt_scene_teapot", "crt_scene_spheres", "crt_scene_soup", "crt_lights_default", "crt_area_table",
     "crt_camera_default", "crt_animate_host", "crt_write_bmp", "crt_host_bvh",
 ]
 
@@ -104,7 +104,7 @@ for _name, _args in {
     "crt_load_obj": [C.c_char_p, _vp, _vp, _i], "crt_scene_teapot": [C.c_char_p, _i, _vp, _i],
     "crt_scene_spheres": [_i, C.c_uint32, _vp], "crt_scene_soup": [_i, C.c_uint32, _vp],
     "crt_host_bvh": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i],
-    "crt_lights_default": [_vp], "crt_animate_host": [_vp, _i], "crt_write_bmp": [C.c_char_p, _vp, _i, _i],
+    "crt_lights_default": [_vp], "crt_area_table": [_vp, _i], "crt_animate_host": [_vp, _i], "crt_write_bmp": [C.c_char_p, _vp, _i, _i],
 }.items():
     getattr(lib, _name).restype = _i
     getattr(lib, _name).argtypes = _args
@@ -164,6 +164,15 @@ def scene_soup(ntris, seed=1):
 def default_lights():
     out = np.zeros(2, LIGHT_DTYPE)
     lib.crt_lights_default(_ptr(out))
+    return out
+
+
+def area_table(n=1024):
+    """The unit-disk sample table of the area lights (include/crt.h: crt_area_table): n x (u, cos, sin)."""
+    out = np.zeros((n, 3), np.float32)
+    rc = lib.crt_area_table(_ptr(out), n)
+    if rc < 0:
+        raise CrtError(rc, "crt_area_table")
     return out
 
 

@@ -64,6 +64,7 @@ struct crt_ctx {
     int32_t* hitSlot = nullptr; float* hitT = nullptr;
     float4 *rc = nullptr, *contrib = nullptr, *shO = nullptr, *shD = nullptr, *accum = nullptr, *sum = nullptr;
     uint8_t* shflag = nullptr;
+    float4* d_area_table = nullptr;      /* unit-disk samples of the area lights, uploaded on first use */
     uint8_t* d_bgr = nullptr; size_t bgr_cap = 0;
     int32_t* cap_ids = nullptr; float* cap_ts = nullptr; size_t cap_planes = 0; size_t cap_npix = 0;
     uint32_t* d_tiles = nullptr; size_t tiles_cap = 0; std::vector<uint32_t> tiles; crt_params tiles_for{}; int64_t owned_pixels = 0;
@@ -333,7 +334,7 @@ void crt_destroy(crt_ctx* c) {
                     c->coef[0], c->coef[1], c->pix[0], c->pix[1], c->hitSlot, c->hitT, c->rc, c->contrib, c->shO, c->shD,
                     c->accum, c->sum, c->shflag, c->d_bgr, c->cap_ids, c->cap_ts, c->d_tiles, c->d_ctr, c->d_status,
                     c->d_testctr, c->d_ovf, c->d_sortkeys, c->d_sortperm, c->d_sorthist, c->d_sortkeys2, c->d_sortperm2,
-                    c->d_lbvh, c->d_lbvh_nodes, c->d_lbvh_s2s};
+                    c->d_lbvh, c->d_lbvh_nodes, c->d_lbvh_s2s, c->d_area_table};
     for (void* p : ptrs) if (p) hipFree(p);
     for (uint32_t* q : c->tl_ids) if (q) hipFree(q);
     for (hipEvent_t e : c->evpool) hipEventDestroy(e);
@@ -348,6 +349,7 @@ void crt_params_default(crt_params* p) {
     p->width = 720; p->height = 360;        /* main.cu:141-142 */
     p->bounces = 2;                          /* Ray.cu:27 */
     p->spp = 1; p->tile_w = 32; p->tile_h = 32; p->rank = 0; p->nranks = 1; p->sort_rays = 0;
+    p->area_samples = 30;                    /* lightSamples, Ray.cu:566 */
 }
 
 int crt_set_counting(crt_ctx* c, int on) { if (!c) return CRT_ERR_ARG; c->counting = on != 0; return CRT_OK; }
@@ -694,7 +696,30 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
     const size_t cap = (size_t)fp.ntiles_owned * p->tile_w * p->tile_h;
     const size_t npix = (size_t)p->width * p->height;
     const int spp = fp.spp_n * fp.spp_n;
-    rc = ensure_frame(c, cap > 0 ? cap : 64, npix, p->bounces, c->lights.n, spp > 1);
+    /* light slots: one per directional / point light, area_samples per area light */
+    LightsParam lights = c->lights;
+    lights.area_samples = p->area_samples > 0 ? p->area_samples : 30;
+    lights.nslots = 0;
+    bool any_area = false;
+    for (int j = 0; j < lights.n; j++) {
+        lights.slot_base[j] = lights.nslots;
+        lights.nslots += lights.l[j].area ? lights.area_samples : 1;
+        any_area = any_area || lights.l[j].area;
+    }
+    if (any_area) {
+        if (lights.area_samples > kAreaSamplesMax) return fail(c, CRT_ERR_ARG, "render: area_samples must be 1..64");
+        if ((uint64_t)lights.nslots * (cap > 0 ? cap : 64) >= (1ull << 31))
+            return fail(c, CRT_ERR_ARG, "render: area_samples x lights x pixels of this rank exceeds 2^31 shadow rays per bounce: render in more tiles/ranks");
+        if (!c->d_area_table) {
+            std::vector<float> tab((size_t)kAreaTable * 3);
+            crt_area_table(tab.data(), kAreaTable);
+            std::vector<float4> t4(kAreaTable);
+            for (int i = 0; i < kAreaTable; i++) t4[i] = make_float4(tab[3 * i], tab[3 * i + 1], tab[3 * i + 2], 0.f);
+            if ((rc = realloc_exact(c, c->d_area_table, (size_t)kAreaTable))) return rc;
+            HIPCHECK(c, hipMemcpy(c->d_area_table, t4.data(), sizeof(float4) * kAreaTable, hipMemcpyHostToDevice));
+        }
+    }
+    rc = ensure_frame(c, cap > 0 ? cap : 64, npix, p->bounces, lights.nslots, spp > 1);
     if (rc) return rc;
     if (!dev_bgr) {
         rc = ensure(c, c->d_bgr, c->bgr_cap, npix * 3);
@@ -702,7 +727,7 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
         dev_bgr = c->d_bgr;
     }
     if (p->sort_rays) {
-        const size_t need = c->cap * (size_t)(c->lights.n > 1 ? c->lights.n : 1);
+        const size_t need = c->cap * (size_t)(lights.nslots > 1 ? lights.nslots : 1);
         if (need > c->sort_cap || !c->d_sortkeys) {
             if ((rc = realloc_exact(c, c->d_sortkeys, need))) return rc;
             if ((rc = realloc_exact(c, c->d_sortperm, need))) return rc;
@@ -730,7 +755,7 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
         int cur = 0;
         FrameBuffers fb{};
         fb.hitSlot = c->hitSlot; fb.hitT = c->hitT; fb.rc = c->rc; fb.contrib = c->contrib; fb.shflag = c->shflag;
-        fb.shO = c->shO; fb.shD = c->shD; fb.accum = c->accum; fb.cap_ids = c->cap_ids; fb.cap_ts = c->cap_ts;
+        fb.shO = c->shO; fb.shD = c->shD; fb.area_table = c->d_area_table; fb.accum = c->accum; fb.cap_ids = c->cap_ids; fb.cap_ts = c->cap_ts;
         fb.cap = (uint32_t)c->cap; fb.cap_stride = (uint32_t)npix; fb.tile_ids = c->d_tiles;
         auto bind = [&](int k) {
             fb.rayO = c->rayO[k]; fb.rayD = c->rayD[k]; fb.coef = c->coef[k]; fb.pix = c->pix[k];
@@ -755,10 +780,10 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
                 TraceArgs ta{};
                 common(ta, 2 * b);
                 ta.rayO = fb.rayO; ta.rayD = fb.rayD; ta.count = ctr + b;
-                launch_trace(ta, c->lights, TRACE_NEAREST, c->counting, wide, c->grid_blocks, c->stream);
+                launch_trace(ta, TRACE_NEAREST, c->counting, wide, c->grid_blocks, c->stream);
                 mark(c, EV_TRACE_N);
             }
-            launch_shade(fp, fb, sv, c->lights, ctr + b, ctr + b + 1, ctr + 16 + b, c->stream);
+            launch_shade(fp, fb, sv, lights, ctr + b, ctr + b + 1, ctr + 16 + b, c->stream);
             mark(c, EV_SHADE);
             if (wide) {
                 /* ONE launch for the shadow rays of this bounce and the nearest-hit rays of the next: they are
@@ -769,7 +794,7 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
                 if (has_sh) {
                     tm.shO = c->shO; tm.shD = c->shD; tm.shcount = ctr + 16 + b;
                     if (p->sort_rays) {
-                        launch_sort_rays(c->shO, ctr + 16 + b, (uint32_t)(c->cap * (size_t)c->lights.n), d_root_box, c->d_sortkeys, c->d_sorthist,
+                        launch_sort_rays(c->shO, ctr + 16 + b, (uint32_t)(c->cap * (size_t)lights.nslots), d_root_box, c->d_sortkeys, c->d_sorthist,
                                          c->d_sortperm, c->stream);
                         tm.shperm = c->d_sortperm;
                         mark(c, EV_SORT);
@@ -784,7 +809,7 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
                     }
                 }
                 if (has_sh || has_nx) {
-                    launch_trace(tm, c->lights, TRACE_NEAREST, c->counting, true, c->grid_blocks, c->stream);
+                    launch_trace(tm, TRACE_NEAREST, c->counting, true, c->grid_blocks, c->stream);
                     mark(c, has_sh && has_nx ? EV_TRACE_M : (has_sh ? EV_TRACE_S : EV_TRACE_N));
                 }
             } else if (c->lights.n > 0) {
@@ -792,10 +817,10 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
                 common(ts, 2 * b + 1);
                 ts.rayO = c->shO; ts.rayD = c->shD; ts.count = ctr + 16 + b;
                 ts.hitSlot = nullptr; ts.hitT = nullptr; ts.counters = c->d_testctr + 16;
-                launch_trace(ts, c->lights, TRACE_SHADOW, c->counting, false, c->grid_blocks, c->stream);
+                launch_trace(ts, TRACE_SHADOW, c->counting, false, c->grid_blocks, c->stream);
                 mark(c, EV_TRACE_S);
             }
-            launch_resolve(fb, c->lights, ctr + b, c->stream);
+            launch_resolve(fb, lights, ctr + b, c->stream);
             mark(c, EV_RESOLVE);
             cur ^= 1;
         }
@@ -902,7 +927,7 @@ static int trace_hook(crt_ctx* c, const float* org_dir, int n, int32_t* prim_out
         TH(hipMemsetAsync(d_cnt, 0, (1 + 8 * kFetchStride) * 4 + 256, c->stream));
         TH(hipMemcpyAsync(d_cnt, &cnt, 4, hipMemcpyHostToDevice, c->stream));
         TH(hipMemsetAsync(d_flag, 0, (size_t)n, c->stream));
-        launch_pack_rays(d_od, (uint32_t)n, d_o, d_d, c->stream);
+        launch_pack_rays(d_od, (uint32_t)n, d_o, d_d, shadow_out != nullptr, c->stream);
         TraceArgs ta{};
         ta.sv = view_of(c); ta.rayO = d_o; ta.rayD = d_d; ta.count = d_cnt; ta.next = d_cnt + 64;
         ta.hitSlot = d_slot; ta.hitT = d_t; ta.shflag = d_flag; ta.scene_abs = c->scene_abs;
@@ -912,11 +937,10 @@ static int trace_hook(crt_ctx* c, const float* org_dir, int n, int32_t* prim_out
             ta.shO = d_o; ta.shD = d_d; ta.shcount = d_cnt;
             ta.rayO = nullptr; ta.rayD = nullptr; ta.count = nullptr;
         }
-        LightsParam dummy{}; dummy.n = 1;          /* light 0 directional: the Ray.cu:650-656 predicate */
         hipEvent_t e0 = next_event(c), e1 = next_event(c);
         c->evused -= 2;
         TH(hipEventRecord(e0, c->stream));
-        launch_trace(ta, dummy, shadow_out ? TRACE_SHADOW : TRACE_NEAREST, c->counting, c->hdr.mode == CRT_BVH_WIDE, c->grid_blocks, c->stream);
+        launch_trace(ta, shadow_out ? TRACE_SHADOW : TRACE_NEAREST, c->counting, c->hdr.mode == CRT_BVH_WIDE, c->grid_blocks, c->stream);
         TH(hipGetLastError());
         TH(hipEventRecord(e1, c->stream));
         if (shadow_out) TH(hipMemcpyAsync(shadow_out, d_flag, (size_t)n, hipMemcpyDeviceToHost, c->stream));

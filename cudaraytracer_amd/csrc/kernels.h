@@ -65,18 +65,41 @@ struct FrameParams {
     int32_t capture;
 };
 
+/* Shade treats every light as one or more SLOTS: a directional or point light owns one, an area light one per
+ * sample.  Slot s of queue entry i owns contrib/shflag[s * cap + i]. */
 struct LightsParam {
     crt_light l[CRT_MAX_LIGHTS];
     int32_t n;
+    int32_t slot_base[CRT_MAX_LIGHTS];
+    int32_t nslots;
+    int32_t area_samples;             /* shadow rays per area light and shading point (crt_params.area_samples) */
 };
 
+/* A shadow ray carries in rayD.w what the traversal needs to know about its light, as float bits:
+ *   -inf                  directional light: shadowed iff a hit exists and the nearest t > 1e-9 (Ray.cu:650-656)
+ *   +dtoLight (sign 0)    point light: nearest hit, shadowed iff dtoLight > |t * dir| (Ray.cu:621-629)
+ *   -dtoLight (sign 1)    area-light sample: as the point light, and only if the nearest t > 1e-9 (Ray.cu:587-596) */
+constexpr uint32_t kShadowDirectional = 0xff800000u;
+
+/* Area lights (commented out in the reference, Ray.cu:563-603): sample k of a shading point
+ * takes entry (h + k) mod kAreaTable of a table of unit-disk samples (u, cos(theta), sin(theta)) built on the
+ * host, where h hashes (pixel, light, bounce, sub-pixel sample). */
+constexpr int kAreaTable = 1024;
+constexpr int kAreaSamplesMax = 64;
+__host__ __device__ static inline uint32_t area_hash(uint32_t pixel, uint32_t light, uint32_t bounce, uint32_t sample) {
+    uint32_t h = pixel * 0x9E3779B1u + light * 0x85EBCA77u + bounce * 0xC2B2AE3Du + sample * 0x27D4EB2Fu;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+    return h;
+}
+
 /* Per-frame device buffers.  Queue entry i of the current bounce owns rayO/rayD/coef/pix[i];
- * shading writes rc/contrib/shflag at [j*cap + i] for light j. */
+ * shading writes rc at [i] and contrib/shflag at [s*cap + i] for light slot s. */
 struct FrameBuffers {
     float4* rayO; float4* rayD; float4* coef; uint32_t* pix;           /* current queue */
     float4* nrayO; float4* nrayD; float4* ncoef; uint32_t* npix;       /* next-bounce queue */
     int32_t* hitSlot; float* hitT;
     float4* rc; float4* contrib; uint8_t* shflag;
+    const float4* area_table;                                          /* kAreaTable entries (u, cos, sin, 0) */
     float4* shO; float4* shD;                                          /* shadow-ray queue: .w = target / light */
     float4* accum;                                                     /* per pixel float colour (isect.color) */
     int32_t* cap_ids; float* cap_ts;                                   /* capture planes [bounce][pixel] or null */
@@ -105,7 +128,7 @@ struct TraceArgs {
 };
 
 int trace_grid_blocks(int device);
-void launch_trace(const TraceArgs& a, const LightsParam& lights, int mode, bool counting, bool wide, int blocks, hipStream_t s);
+void launch_trace(const TraceArgs& a, int mode, bool counting, bool wide, int blocks, hipStream_t s);
 void launch_quantize(const Node8* nodes, uint32_t nnodes, QNode8* qnodes, uint32_t* status, hipStream_t s);
 void launch_gen_primary(const FrameParams& fp, const FrameBuffers& fb, uint32_t* count, hipStream_t s);
 void launch_shade(const FrameParams& fp, const FrameBuffers& fb, const SceneView& sv, const LightsParam& lights,
@@ -135,7 +158,7 @@ void launch_refit(Node4* nodes, uint32_t nnodes, const Geom* geom, uint32_t* arr
 void launch_refit8(Node8* nodes, uint32_t nnodes, const Geom* geom, uint32_t* arrive, float* root_box, int grow_only,
                    hipStream_t s);
 void launch_slots_to_scene(const int32_t* slots, const uint32_t* sidx, int32_t* out, uint32_t n, hipStream_t s);
-void launch_pack_rays(const float* org_dir, uint32_t n, float4* rayO, float4* rayD, hipStream_t s);
+void launch_pack_rays(const float* org_dir, uint32_t n, float4* rayO, float4* rayD, bool shadow, hipStream_t s);
 void launch_tiles_copy(const FrameParams& fp, const uint32_t* tile_ids, int ntiles, const uint8_t* src, uint8_t* dst,
                        int to_packed, hipStream_t s);
 

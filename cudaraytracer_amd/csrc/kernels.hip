@@ -97,7 +97,7 @@ CRT_DEV bool sphere_test(const GeomRec& g, const vec3& o, const vec3& d, float& 
 #define CRT_TRACE_BOUNDS __launch_bounds__(kTraceBlock)
 #endif
 template <int MODE, bool COUNT>
-__global__ CRT_TRACE_BOUNDS void k_trace(TraceArgs A, LightsParam LP) {
+__global__ CRT_TRACE_BOUNDS void k_trace(TraceArgs A) {
     __shared__ uint32_t s_stack[kStackDepth + 1][kTraceBlock];   /* last row: write-only trash for the branch-free push */
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -120,7 +120,7 @@ __global__ CRT_TRACE_BOUNDS void k_trace(TraceArgs A, LightsParam LP) {
     uint32_t lp = 0, lend = 0;      /* pending primitives of the current leaf */
     int sp = 0;
     int found = 0;          /* SHADOW: a hit with t > 1e-9 exists */
-    int lightj = 0;
+    uint32_t lkind = kShadowDirectional;   /* SHADOW: float bits of the ray's light distance (kernels.h) */
     unsigned long long nbox = 0, ntri = 0, nsph = 0, nvis = 0;
 
     /* take the next item off the stack, or report that the ray is finished */
@@ -189,7 +189,7 @@ __global__ CRT_TRACE_BOUNDS void k_trace(TraceArgs A, LightsParam LP) {
                         } else {
                             ray = idx;
                             o = vec3(ro.x, ro.y, ro.z); d = vec3(rd.x, rd.y, rd.z);
-                            if (MODE == TRACE_SHADOW) { ray = __float_as_uint(ro.w); lightj = (int)__float_as_uint(rd.w); }
+                            if (MODE == TRACE_SHADOW) { ray = __float_as_uint(ro.w); lkind = __float_as_uint(rd.w); }
                             /* clamped reciprocal: a zero component (the centre pixel column has
                              * direction.x == 0 exactly) becomes +-1e20 instead of inf, so 0*inf never appears */
                             float rx = 1.0f / d.x, ry = 1.0f / d.y, rz = 1.0f / d.z;
@@ -299,7 +299,7 @@ __global__ CRT_TRACE_BOUNDS void k_trace(TraceArgs A, LightsParam LP) {
                              * reference would have met first (lower rank in its leaf order) */
                             if (t < tbest || (t == tbest && best >= 0 && A.sv.rank[p] < A.sv.rank[best])) { tbest = t; best = (int)p; }
                         } else {
-                            if (LP.l[lightj].point) {           /* nearest t decides, Ray.cu:621-629 */
+                            if (lkind != kShadowDirectional) {  /* point light or area-light sample: nearest t decides, Ray.cu:621-629 */
                                 if (t < tbest) { tbest = t; best = (int)p; }
                             } else {                              /* Ray.cu:650-656: hit exists and min t > 1e-9 */
                                 if (!(t > 0.000000001f)) { found = 0; finish = true; }
@@ -316,16 +316,16 @@ __global__ CRT_TRACE_BOUNDS void k_trace(TraceArgs A, LightsParam LP) {
                     A.hitT[ray] = tbest;
                 } else {
                     bool shadowed;
-                    if (LP.l[lightj].point) {
+                    if (lkind != kShadowDirectional) {
                         shadowed = false;
                         if (best >= 0) {
-                            const vec3 lpos(LP.l[lightj].position);
+                            /* Ray.cu:625-629; k_shade computed dtoLight from this very origin */
                             const vec3 ipoint = o + tbest * d;
-                            const float ex = o.x - lpos.x, ey = o.y - lpos.y, ez = o.z - lpos.z;
-                            const float dtoLight = sqrtf(ex * ex + ey * ey + ez * ez);
+                            const float dtoLight = __uint_as_float(lkind & 0x7fffffffu);
                             const float fx = ipoint.x - o.x, fy = ipoint.y - o.y, fz = ipoint.z - o.z;
                             const float dtoLightIntersection = sqrtf(fx * fx + fy * fy + fz * fz);
                             shadowed = dtoLight > dtoLightIntersection;
+                            if ((lkind >> 31) && !(tbest > 0.000000001f)) shadowed = false;   /* area samples: Ray.cu:589 */
                         }
                     } else shadowed = (found != 0);
                     if (shadowed) A.shflag[ray] = 1;
@@ -417,7 +417,7 @@ CRT_DEV void slab8(uint32_t& raw, uint32_t wnx, uint32_t wfx, uint32_t wny, uint
 #define CRT_TRACE8_BOUNDS __launch_bounds__(kTraceBlock)
 #endif
 template <bool COUNT>
-__global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
+__global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
     __shared__ uint2 s_stack[kStackDepth8][kTraceBlock];
     __shared__ uint8_t s_perm[8][256];     /* s_perm[R][m]: bit k of m moved to bit k ^ R */
     const int tid = threadIdx.x;
@@ -458,7 +458,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
     uint32_t lp = 0, lend = 0;
     int sp = 0;
     int found = 0;
-    int lightj = 0;
+    uint32_t lkind = kShadowDirectional;   /* shadow lanes: float bits of the ray's light distance (kernels.h) */
     unsigned long long nbox[2] = {0, 0}, ntri[2] = {0, 0}, nsph[2] = {0, 0}, nvis[2] = {0, 0};      /* [0] nearest-hit rays, [1] shadow rays */
     unsigned long long sch[5] = {0, 0, 0, 0, 0}, nzero = 0;
 
@@ -611,7 +611,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
                         if (!shray) {
                             if (t < tbest || (t == tbest && best >= 0 && A.sv.rank[p] < A.sv.rank[best])) { tbest = t; best = (int)p; }
                         } else {
-                            if (LP.l[lightj].point) {
+                            if (lkind != kShadowDirectional) {
                                 if (t < tbest) { tbest = t; best = (int)p; }
                             } else {
                                 if (!(t > 0.000000001f)) { found = 0; finish = true; }
@@ -628,16 +628,16 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
                     A.hitT[ray] = tbest;
                 } else {
                     bool shadowed;
-                    if (LP.l[lightj].point) {
+                    if (lkind != kShadowDirectional) {
                         shadowed = false;
                         if (best >= 0) {
-                            const vec3 lpos(LP.l[lightj].position);
+                            /* Ray.cu:625-629; k_shade computed dtoLight from this very origin */
                             const vec3 ipoint = o + tbest * d;
-                            const float ex = o.x - lpos.x, ey = o.y - lpos.y, ez = o.z - lpos.z;
-                            const float dtoLight = sqrtf(ex * ex + ey * ey + ez * ez);
+                            const float dtoLight = __uint_as_float(lkind & 0x7fffffffu);
                             const float fx = ipoint.x - o.x, fy = ipoint.y - o.y, fz = ipoint.z - o.z;
                             const float dtoLightIntersection = sqrtf(fx * fx + fy * fy + fz * fz);
                             shadowed = dtoLight > dtoLightIntersection;
+                            if ((lkind >> 31) && !(tbest > 0.000000001f)) shadowed = false;   /* area samples: Ray.cu:589 */
                         }
                     } else shadowed = (found != 0);
                     if (shadowed) A.shflag[ray & 0x7fffffffu] = 1;
@@ -656,7 +656,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A, LightsParam LP) {
             } else {
                 ray = idx;
                 o = vec3(ro.x, ro.y, ro.z); d = vec3(rd.x, rd.y, rd.z);
-                if (shray) { ray = __float_as_uint(ro.w) | 0x80000000u; lightj = (int)__float_as_uint(rd.w); }
+                if (shray) { ray = __float_as_uint(ro.w) | 0x80000000u; lkind = __float_as_uint(rd.w); }
                 /* v_rcp_f32 (1 ulp) instead of an IEEE division: the box test only has to be
                  * conservative and the pad below is 1e4 times that error */
                 float rx = __builtin_amdgcn_rcpf(d.x), ry = __builtin_amdgcn_rcpf(d.y), rz = __builtin_amdgcn_rcpf(d.z);
@@ -705,18 +705,18 @@ int trace_grid_blocks(int device) {
     return p.multiProcessorCount * per_cu;
 }
 
-void launch_trace(const TraceArgs& a, const LightsParam& lights, int mode, bool counting, bool wide, int blocks, hipStream_t s) {
+void launch_trace(const TraceArgs& a, int mode, bool counting, bool wide, int blocks, hipStream_t s) {
     dim3 g(blocks), b(kTraceBlock);
     if (wide) {          /* k_trace8 serves both of its queues in one launch; `mode` is not used */
-        if (counting) hipLaunchKernelGGL((k_trace8<true>), g, b, 0, s, a, lights);
-        else hipLaunchKernelGGL((k_trace8<false>), g, b, 0, s, a, lights);
+        if (counting) hipLaunchKernelGGL((k_trace8<true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((k_trace8<false>), g, b, 0, s, a);
     } else {
         if (mode == TRACE_NEAREST) {
-            if (counting) hipLaunchKernelGGL((k_trace<TRACE_NEAREST, true>), g, b, 0, s, a, lights);
-            else hipLaunchKernelGGL((k_trace<TRACE_NEAREST, false>), g, b, 0, s, a, lights);
+            if (counting) hipLaunchKernelGGL((k_trace<TRACE_NEAREST, true>), g, b, 0, s, a);
+            else hipLaunchKernelGGL((k_trace<TRACE_NEAREST, false>), g, b, 0, s, a);
         } else {
-            if (counting) hipLaunchKernelGGL((k_trace<TRACE_SHADOW, true>), g, b, 0, s, a, lights);
-            else hipLaunchKernelGGL((k_trace<TRACE_SHADOW, false>), g, b, 0, s, a, lights);
+            if (counting) hipLaunchKernelGGL((k_trace<TRACE_SHADOW, true>), g, b, 0, s, a);
+            else hipLaunchKernelGGL((k_trace<TRACE_SHADOW, false>), g, b, 0, s, a);
         }
     }
 }
@@ -1083,10 +1083,10 @@ __global__ __launch_bounds__(256) void k_shade(FrameParams P, FrameBuffers B, Sc
         for (int j = 0; j < LP.n; j++) {
             bool want = false;
             if (!dead) {
-                if (LP.l[j].point) want = true;
+                if (LP.l[j].area || LP.l[j].point) want = true;
                 else want = !((double)dot(normalize(vec3(LP.l[j].direction)), N) > -0.00001);
             }
-            wave_sh += (uint32_t)__popcll(__ballot(want));
+            wave_sh += (uint32_t)__popcll(__ballot(want)) * (LP.l[j].area ? (uint32_t)LP.area_samples : 1u);
         }
         const unsigned long long emit_mask = __ballot(emit);
         if (lane == 0) { s_cnt[0][wv] = wave_sh; s_cnt[1][wv] = (uint32_t)__popcll(emit_mask); }
@@ -1106,44 +1106,63 @@ __global__ __launch_bounds__(256) void k_shade(FrameParams P, FrameBuffers B, Sc
         if (!dead) direction = normalize(incident);
         for (int j = 0; j < LP.n; j++) {
             const crt_light& l = LP.l[j];
-            bool want = false;
-            vec3 toLight, sorg;
-            if (!dead) {
-                vec3 reflectFromLight;
-                float distance;
-                uint8_t flag = 0;
-                if (l.point) {
-                    const vec3 lpos(l.position);
-                    const float ex = intersection.x - lpos.x, ey = intersection.y - lpos.y, ez = intersection.z - lpos.z;
-                    const float dd = sqrtf(ex * ex + ey * ey + ez * ez);
-                    distance = 1.0f / (l.constantTerm + l.linearTerm * dd + l.quadraticTerm * (dd * dd));
-                    if (distance > 1.5f) distance = .5f;
-                    toLight = normalize(lpos - intersection);
-                    reflectFromLight = -toLight;
-                    intersection = intersection + .01f * N;           /* cumulative, Ray.cu:620 */
-                    want = true;
-                } else {
-                    distance = 1.0f;
-                    toLight = -normalize(vec3(l.direction));
-                    reflectFromLight = normalize(vec3(l.direction));
-                    const float dotP = dot(reflectFromLight, N);
-                    if ((double)dotP > -0.00001) flag = 1;            /* faces away: shadowed without a ray */
-                    else want = true;
+            /* an area light is a disk of l.radius in the XZ plane about l.position, sampled area_samples times
+             * (Ray.cu:563-603, commented out there); every sample is shaded like an unattenuated point light */
+            const int ns = l.area ? LP.area_samples : 1;
+            const uint32_t ah = l.area ? area_hash(pix, (uint32_t)j, (uint32_t)P.bounce, (uint32_t)P.sample) : 0u;
+            for (int k = 0; k < ns; k++) {
+                const size_t plane = (size_t)(LP.slot_base[j] + k) * B.cap + i;
+                bool want = false;
+                vec3 toLight, sorg;
+                uint32_t lbits = kShadowDirectional;
+                if (!dead) {
+                    vec3 reflectFromLight;
+                    float distance;
+                    uint8_t flag = 0;
+                    if (l.area || l.point) {
+                        vec3 lpos(l.position);
+                        if (l.area) {
+                            const float4 e = B.area_table[(ah + (uint32_t)k) & (uint32_t)(kAreaTable - 1)];
+                            const float radius = e.x * l.radius;                  /* Ray.cu:569-575 */
+                            lpos.x = lpos.x + radius * e.y;
+                            lpos.z = lpos.z + radius * e.z;
+                            distance = 1.0f;
+                        } else {
+                            const float ex = intersection.x - lpos.x, ey = intersection.y - lpos.y, ez = intersection.z - lpos.z;
+                            const float dd = sqrtf(ex * ex + ey * ey + ez * ez);
+                            distance = 1.0f / (l.constantTerm + l.linearTerm * dd + l.quadraticTerm * (dd * dd));
+                            if (distance > 1.5f) distance = .5f;
+                        }
+                        toLight = normalize(lpos - intersection);
+                        reflectFromLight = -toLight;
+                        intersection = intersection + .01f * N;           /* cumulative, Ray.cu:585,620 */
+                        /* dtoLight of Ray.cu:592,626, from the origin the shadow ray starts at */
+                        const float fx = intersection.x - lpos.x, fy = intersection.y - lpos.y, fz = intersection.z - lpos.z;
+                        lbits = __float_as_uint(sqrtf(fx * fx + fy * fy + fz * fz)) | (l.area ? 0x80000000u : 0u);
+                        want = true;
+                    } else {
+                        distance = 1.0f;
+                        toLight = -normalize(vec3(l.direction));
+                        reflectFromLight = normalize(vec3(l.direction));
+                        const float dotP = dot(reflectFromLight, N);
+                        if ((double)dotP > -0.00001) flag = 1;            /* faces away: shadowed without a ray */
+                        else want = true;
+                    }
+                    sorg = intersection;
+                    const float sdot = dot(reflect(reflectFromLight, N), -direction);
+                    const float spec = (float)pow((double)sdot, (double)shininess);
+                    const vec3 X = (.6f * diffuse * gmax(dot(toLight, N), 0.0f) + .2f * specular * spec);
+                    B.contrib[plane] = make_float4(X.x, X.y, X.z, distance);
+                    B.shflag[plane] = flag;
                 }
-                sorg = intersection;
-                const float sdot = dot(reflect(reflectFromLight, N), -direction);
-                const float spec = (float)pow((double)sdot, (double)shininess);
-                const vec3 X = (.6f * diffuse * gmax(dot(toLight, N), 0.0f) + .2f * specular * spec);
-                B.contrib[(size_t)j * B.cap + i] = make_float4(X.x, X.y, X.z, distance);
-                B.shflag[(size_t)j * B.cap + i] = flag;
+                const unsigned long long wm = __ballot(want);
+                if (want) {
+                    const uint32_t ks = sh_run + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull));
+                    B.shO[ks] = make_float4(sorg.x, sorg.y, sorg.z, __uint_as_float((uint32_t)plane));
+                    B.shD[ks] = make_float4(toLight.x, toLight.y, toLight.z, __uint_as_float(lbits));
+                }
+                sh_run += (uint32_t)__popcll(wm);
             }
-            const unsigned long long wm = __ballot(want);
-            if (want) {
-                const uint32_t ks = sh_run + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull));
-                B.shO[ks] = make_float4(sorg.x, sorg.y, sorg.z, __uint_as_float((uint32_t)((size_t)j * B.cap + i)));
-                B.shD[ks] = make_float4(toLight.x, toLight.y, toLight.z, __uint_as_float((uint32_t)j));
-            }
-            sh_run += (uint32_t)__popcll(wm);
         }
 
         /* ---- reflected ray, Ray.cu:494-496 / 519-520; paths whose coefficient is zero end here ---- */
@@ -1174,10 +1193,24 @@ __global__ __launch_bounds__(256) void k_resolve(FrameBuffers B, LightsParam LP,
         if (rc4.w == 0.f) continue;
         vec3 color;
         for (int j = 0; j < LP.n; j++) {
-            const float4 c = B.contrib[(size_t)j * B.cap + i];
-            float distance = c.w;
-            if (B.shflag[(size_t)j * B.cap + i]) distance = distance * 0;
-            color += distance * vec3(LP.l[j].color) * vec3(c.x, c.y, c.z);
+            const vec3 lcolor(LP.l[j].color);
+            if (LP.l[j].area) {                       /* Ray.cu:565-601: mean over the samples */
+                vec3 avgcolor;
+                for (int k = 0; k < LP.area_samples; k++) {
+                    const size_t plane = (size_t)(LP.slot_base[j] + k) * B.cap + i;
+                    const float4 c = B.contrib[plane];
+                    float distance = c.w;
+                    if (B.shflag[plane]) distance = distance * 0;
+                    avgcolor += distance * lcolor * vec3(c.x, c.y, c.z);
+                }
+                color += avgcolor / (float)LP.area_samples;
+            } else {
+                const size_t plane = (size_t)LP.slot_base[j] * B.cap + i;
+                const float4 c = B.contrib[plane];
+                float distance = c.w;
+                if (B.shflag[plane]) distance = distance * 0;
+                color += distance * lcolor * vec3(c.x, c.y, c.z);
+            }
         }
         const uint32_t pix = B.pix[i];
         if (pix == 0xffffffffu) continue;
@@ -1439,14 +1472,15 @@ __global__ void k_slots_to_scene(const int32_t* slots, const uint32_t* sidx, int
 void launch_slots_to_scene(const int32_t* slots, const uint32_t* sidx, int32_t* out, uint32_t n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_slots_to_scene, dim3((n + 255) / 256), dim3(256), 0, s, slots, sidx, out, n);
 }
-__global__ void k_pack_rays(const float* od, uint32_t n, float4* rayO, float4* rayD) {
+__global__ void k_pack_rays(const float* od, uint32_t n, float4* rayO, float4* rayD, uint32_t dw) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     rayO[i] = make_float4(od[6 * i], od[6 * i + 1], od[6 * i + 2], __uint_as_float(i));
-    rayD[i] = make_float4(od[6 * i + 3], od[6 * i + 4], od[6 * i + 5], 0.f);
+    rayD[i] = make_float4(od[6 * i + 3], od[6 * i + 4], od[6 * i + 5], __uint_as_float(dw));
 }
-void launch_pack_rays(const float* org_dir, uint32_t n, float4* rayO, float4* rayD, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(k_pack_rays, dim3((n + 255) / 256), dim3(256), 0, s, org_dir, n, rayO, rayD);
+void launch_pack_rays(const float* org_dir, uint32_t n, float4* rayO, float4* rayD, bool shadow, hipStream_t s) {
+    /* shadow rays of the parity hook follow the directional-light predicate (Ray.cu:650-656) */
+    if (n) hipLaunchKernelGGL(k_pack_rays, dim3((n + 255) / 256), dim3(256), 0, s, org_dir, n, rayO, rayD, shadow ? kShadowDirectional : 0u);
 }
 
 }  // namespace crt

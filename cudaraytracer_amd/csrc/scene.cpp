@@ -125,6 +125,23 @@ int crt_lights_default(crt_light* out) {
     return 2;
 }
 
+/* Unit-disk samples of the area lights (Ray.cu:569-573: radius = U * l.radius, theta = U * 2*PI, offset
+ * (radius*cos(theta), 0, radius*sin(theta))).  The reference draws U from curand per thread; here the draws are
+ * a fixed table from the 32-bit LCG x <- 1664525 x + 1013904223, x0 = 0x2545F491, U = (x >> 8) / 2^24. */
+int crt_area_table(float* out3, int n) {
+    if (!out3 || n < 0 || n > 1024) return CRT_ERR_ARG;
+    uint32_t x = 0x2545F491u;
+    for (int i = 0; i < n; i++) {
+        x = x * 1664525u + 1013904223u;
+        const float u1 = (float)(x >> 8) * (1.0f / 16777216.0f);
+        x = x * 1664525u + 1013904223u;
+        const float u2 = (float)(x >> 8) * (1.0f / 16777216.0f);
+        const float theta = u2 * (2 * 3.14159265359);     /* PI of Ray.cu:16; the product is a double, stored as float */
+        out3[3 * i] = u1; out3[3 * i + 1] = cosf(theta); out3[3 * i + 2] = sinf(theta);
+    }
+    return n;
+}
+
 void crt_camera_default(crt_camera* c) { set3(c->position, 0, 50, 250); set3(c->target, 0, 0, 0); }
 
 static inline float u01(std::mt19937& g) { return (float)(g() >> 8) * (1.0f / 16777216.0f); }

@@ -52,7 +52,9 @@ typedef struct crt_light {
     int32_t point;           /* non-zero: point light (Ray.cu:604-632), else directional (Ray.cu:633-658) */
     float constantTerm, linearTerm, quadraticTerm;
     float position[3];
-    int32_t area;            /* carried; area lights are commented out in the reference (Ray.cu:563-603) */
+    int32_t area;            /* non-zero: area light (takes precedence over `point`): a disk of `radius` in the XZ plane
+                              * about `position`, sampled crt_params.area_samples times per shading point.  The
+                              * reference has this branch commented out (Ray.cu:563-603); see crt_area_table */
     float radius;
 } crt_light;
 
@@ -72,7 +74,8 @@ typedef struct crt_params {
     int32_t rank, nranks;    /* this context renders tiles t with crt_tile_owner(t, nranks) == rank; 0, 1 */
     int32_t sort_rays;       /* 0/1: visit reflection and shadow rays in Morton order of their origin's cell (32^3 grid over
                               * the scene box; wide BVH only).  Changes the visiting order only, never the image. */
-    int32_t reserved[7];
+    int32_t area_samples;    /* shadow rays per area light and shading point, 1..64; 0 = 30 (lightSamples, Ray.cu:566) */
+    int32_t reserved[6];
 } crt_params;
 
 typedef struct crt_stats {
@@ -181,6 +184,10 @@ int crt_load_obj(const char* path, float* verts3, float* norms3, int max_corners
 int crt_scene_teapot(const char* obj_path, int with_sphere, crt_prim* out, int cap);  /* returns prim count */
 int crt_scene_spheres(int n, uint32_t seed, crt_prim* out);
 int crt_scene_soup(int ntris, uint32_t seed, crt_prim* out);
+/* The unit-disk sample table of the area lights: n <= 1024 entries of (u, cos(theta), sin(theta)) with u, theta/2pi
+ * from a 32-bit LCG (Ray.cu:569-573 draws them from curand).  Sample k of a shading point is entry
+ * (hash(pixel, light, bounce, sub-sample) + k) mod 1024, placed at position + u*radius*(cos, 0, sin). */
+int crt_area_table(float* out3, int n);
 int crt_lights_default(crt_light* out2);                                              /* l1, l3 of main.cu:465-488 */
 void crt_camera_default(crt_camera*);                                                  /* main.cu:459,508 */
 int crt_animate_host(crt_prim* prims, int n);                                          /* main.cu:545-573 */

@@ -28,6 +28,7 @@
 #include <deque>
 #include <thread>
 #include <atomic>
+#include <mutex>
 #include <string>
 
 namespace {
@@ -302,7 +303,37 @@ int ray_intersection(const orc_scene* sc, const RayS& ray, RayS& refl, IsectS& i
 }
 
 /* ---------------- Ray.cu:546-663 Shade, one intersection ---------------- */
-void shade(const orc_scene* sc, IsectS& is, const orc_light* lights, int numlights, bool live, Counters& k) {
+/* Area-light samples.  The reference draws radius and theta from curand (Ray.cu:569-570, commented out); this
+ * restatement fixes the draws so that two implementations can agree: a table of 1024 (U1, cos, sin) triples
+ * from the LCG x <- 1664525 x + 1013904223 (x0 = 0x2545F491, U = (x >> 8) / 2^24), and sample k of a shading
+ * point reads entry (hash(pixel, light, bounce, 0) + k) mod 1024. */
+#define ORC_PI 3.14159265359
+static const int kAreaTableN = 1024;
+static void area_table(float* out3, int n) {
+    uint32_t x = 0x2545F491u;
+    for (int i = 0; i < n; i++) {
+        x = x * 1664525u + 1013904223u;
+        float u1 = (float)(x >> 8) * (1.0f / 16777216.0f);
+        x = x * 1664525u + 1013904223u;
+        float u2 = (float)(x >> 8) * (1.0f / 16777216.0f);
+        float theta = u2 * (2 * ORC_PI);                       /* Ray.cu:570 */
+        out3[3 * i] = u1; out3[3 * i + 1] = cosf(theta); out3[3 * i + 2] = sinf(theta);
+    }
+}
+static const float* area_table_get() {
+    static float tab[kAreaTableN * 3];
+    static std::once_flag once;
+    std::call_once(once, [] { area_table(tab, kAreaTableN); });
+    return tab;
+}
+static uint32_t area_hash(uint32_t pixel, uint32_t light, uint32_t bounce, uint32_t sample) {
+    uint32_t h = pixel * 0x9E3779B1u + light * 0x85EBCA77u + bounce * 0xC2B2AE3Du + sample * 0x27D4EB2Fu;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+    return h;
+}
+
+void shade(const orc_scene* sc, IsectS& is, const orc_light* lights, int numlights, bool live, Counters& k,
+           int lightSamples = 30, uint32_t pixel = 0, uint32_t bounce = 0) {
     const float RAY_EPSILON = 0.000000001f;
     ov3 color;
     ov3 direction = onormalize(is.incidentDirection);
@@ -313,7 +344,44 @@ void shade(const orc_scene* sc, IsectS& is, const orc_light* lights, int numligh
     for (int j = 0; j < numlights; j++) {
         const orc_light& l = lights[j];
         ov3 lpos(l.position), lcol(l.color), ldir(l.direction);
-        if (l.point) {
+        if (l.area) {
+            /* Ray.cu:563-603, commented out in the reference.  Restated with three stated departures: the draws
+             * come from the table above; the sample offset is taken from the light's centre (the block adds it to
+             * l.position cumulatively, a random walk); the light is skipped by the point/directional branches
+             * below (the block falls through into them). */
+            const float* tab = area_table_get();
+            const uint32_t h = area_hash(pixel, (uint32_t)j, bounce, 0u);
+            ov3 avgcolor;
+            for (int si = 0; si < lightSamples; si++) {
+                const float* e = tab + 3 * ((h + (uint32_t)si) & (uint32_t)(kAreaTableN - 1));
+                float radius = e[0] * l.radius;
+                float x = radius * e[1];
+                float z = radius * e[2];
+                ov3 spos = lpos;
+                spos.x = spos.x + x;
+                spos.z = spos.z + z;
+                toLight = onormalize(spos - intersection);
+                reflectFromLight = -toLight;
+                distance = 1.0f;
+                float minT = 1000000000; int obj = -1; ov3 mn, mi; bool shadow = false;
+                intersection = intersection + .01f * normal;
+                k.traversals++; k.shadow++; if (live) k.live++;
+                bvh_traverse(sc, intersection, toLight, sc->root, shadow, minT, obj, mn, mi, k);
+                if (shadow) {
+                    if (minT > RAY_EPSILON) {
+                        ov3 ipoint = intersection + minT * toLight;
+                        float ax = intersection.x - spos.x, ay = intersection.y - spos.y, az = intersection.z - spos.z;
+                        float dtoLight = sqrtf(ax * ax + ay * ay + az * az);
+                        float bx = ipoint.x - intersection.x, by = ipoint.y - intersection.y, bz = ipoint.z - intersection.z;
+                        float dtoLightIntersection = sqrtf(bx * bx + by * by + bz * bz);
+                        if (dtoLight > dtoLightIntersection) distance = distance * 0;
+                    }
+                }
+                avgcolor += distance * lcol * (.6f * is.diffuse * omax(odot(toLight, normal), 0.0f) +
+                                               .2f * is.specular * powf(odot(oreflect(reflectFromLight, normal), -direction), is.shininess));
+            }
+            color += avgcolor / (float)lightSamples;
+        } else if (l.point) {
             float dx = intersection.x - lpos.x, dy = intersection.y - lpos.y, dz = intersection.z - lpos.z;
             float d = sqrtf(dx * dx + dy * dy + dz * dz);
             distance = 1.0f / (l.constantTerm + l.linearTerm * d + l.quadraticTerm * (d * d));
@@ -357,7 +425,6 @@ void shade(const orc_scene* sc, IsectS& is, const orc_light* lights, int numligh
 
 /* ---------------- Ray.cu:684-689 camera basis ---------------- */
 struct Camera { ov3 L, u, v, pos; };
-#define ORC_PI 3.14159265359
 Camera make_camera(const ov3& cameraPosition, const ov3& cameraDirection, float width, float height) {
     Camera c;
     ov3 n = onormalize(cameraPosition - cameraDirection);
@@ -749,6 +816,14 @@ void orc_primary_rays(const float cam[3], const float target[3], int width, int 
 int orc_render(orc_scene* s, const orc_light* lights, int nlights, const float cam[3], const float target[3],
                int width, int height, int bounces, const int32_t* rect, unsigned char* bgr, float* color_f32,
                int32_t* ids, float* ts, int nthreads) {
+    return orc_render_area(s, lights, nlights, cam, target, width, height, bounces, rect, bgr, color_f32, ids, ts, nthreads, 30);
+}
+
+void orc_area_table(float* out3, int n) { area_table(out3, n); }
+
+int orc_render_area(orc_scene* s, const orc_light* lights, int nlights, const float cam[3], const float target[3],
+                    int width, int height, int bounces, const int32_t* rect, unsigned char* bgr, float* color_f32,
+                    int32_t* ids, float* ts, int nthreads, int area_samples) {
     if (!s->root) return -1;
     Camera c = make_camera(ov3(cam), ov3(target), (float)width, (float)height);
     int x0 = 0, y0 = 0, x1 = width, y1 = height;
@@ -777,7 +852,7 @@ int orc_render(orc_scene* s, const orc_light* lights, int nlights, const float c
                 if (ids) ids[(size_t)bn * total + i] = id;
                 if (ts) ts[(size_t)bn * total + i] = tHit;
                 if (id == -1) { is.color = keep; dead = true; continue; }   /* G6: defined as path end */
-                shade(s, is, lights, nlights, live, k);
+                shade(s, is, lights, nlights, live, k, area_samples, (uint32_t)i, (uint32_t)bn);
                 ray = refl;
             }
             ov3 col = is.color;

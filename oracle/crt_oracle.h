@@ -99,6 +99,13 @@ void orc_trace_brute(orc_scene*, const float* rays, int n, int32_t* prim_out, fl
 int orc_render(orc_scene*, const orc_light* lights, int nlights, const float cam[3], const float target[3],
                int width, int height, int bounces, const int32_t* rect, unsigned char* bgr, float* color_f32,
                int32_t* ids, float* ts, int nthreads);
+/* the same with area lights (orc_light.area != 0): area_samples shadow rays per light and shading point.
+ * Ray.cu:563-603 is commented out in the reference, so there is no reference behaviour to pin this against; the
+ * restatement and its departures are described at shade() in crt_oracle.cpp. */
+int orc_render_area(orc_scene*, const orc_light* lights, int nlights, const float cam[3], const float target[3],
+                    int width, int height, int bounces, const int32_t* rect, unsigned char* bgr, float* color_f32,
+                    int32_t* ids, float* ts, int nthreads, int area_samples);
+void orc_area_table(float* out3, int n);                   /* n <= 1024 entries (U1, cos(theta), sin(theta)) */
 void orc_primary_rays(const float cam[3], const float target[3], int width, int height, float* rays6);
 void orc_stats_get(orc_scene*, orc_stats* out);
 void orc_stats_reset(orc_scene*);

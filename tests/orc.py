@@ -59,6 +59,7 @@ def lib():
             "orc_num_nodes": [vp], "orc_num_leaves": [vp],
             "orc_tree_dump": [vp] * 9,
             "orc_render": [vp, vp, i, vp, vp, i, i, i, vp, vp, vp, vp, vp, i],
+            "orc_render_area": [vp, vp, i, vp, vp, i, i, i, vp, vp, vp, vp, vp, i, i],
             "orc_load_obj": [C.c_char_p, vp, vp, i],
         }.items():
             getattr(L, name).restype = i
@@ -67,7 +68,7 @@ def lib():
             "orc_scene_get": [vp, vp], "orc_scene_set": [vp, vp], "orc_refit": [vp], "orc_animate": [vp],
             "orc_trace": [vp, vp, i, vp, vp, vp, vp, i], "orc_trace_brute": [vp, vp, i, vp, vp, i],
             "orc_primary_rays": [vp, vp, i, i, vp], "orc_stats_get": [vp, vp], "orc_stats_reset": [vp],
-            "orc_math_probe": [vp, i, vp],
+            "orc_math_probe": [vp, i, vp], "orc_area_table": [vp, i],
         }.items():
             getattr(L, name).restype = None
             getattr(L, name).argtypes = args
@@ -121,6 +122,12 @@ def load_obj(path):
     v = np.zeros((n, 3), np.float32); nm = np.zeros((n, 3), np.float32)
     assert lib().orc_load_obj(path.encode(), _p(v), _p(nm), n) == n
     return v, nm
+
+
+def area_table(n=1024):
+    out = np.zeros((n, 3), np.float32)
+    lib().orc_area_table(_p(out), n)
+    return out
 
 
 def primary_rays(cam, target, w, h):
@@ -194,15 +201,16 @@ class Scene:
         lib().orc_trace_brute(self.h, _p(rays6), n, _p(ids), _p(ts), nthreads)
         return ids, ts
 
-    def render(self, lights, cam, target, w, h, bounces, rect=None, nthreads=8, want_color=False, want_ids=False):
+    def render(self, lights, cam, target, w, h, bounces, rect=None, nthreads=8, want_color=False, want_ids=False,
+               area_samples=30):
         lights = np.ascontiguousarray(lights, LIGHT_DTYPE)
         bgr = np.zeros((h, w, 3), np.uint8)
         col = np.zeros((h * w, 3), np.float32) if want_color else None
         ids = np.zeros((bounces, h * w), np.int32) if want_ids else None
         ts = np.zeros((bounces, h * w), np.float32) if want_ids else None
         r = np.ascontiguousarray(rect, np.int32) if rect is not None else None
-        rc = lib().orc_render(self.h, _p(lights), len(lights), _p(f3(cam)), _p(f3(target)), w, h, bounces, _p(r),
-                              _p(bgr), _p(col), _p(ids), _p(ts), nthreads)
+        rc = lib().orc_render_area(self.h, _p(lights), len(lights), _p(f3(cam)), _p(f3(target)), w, h, bounces, _p(r),
+                                   _p(bgr), _p(col), _p(ids), _p(ts), nthreads, area_samples)
         assert rc == 0
         return dict(bgr=bgr, color=col, ids=ids, ts=ts)
 

@@ -167,6 +167,16 @@ def test_coincident_centroids_do_not_hang(crt):
     assert e.value.code == -6
 
 
+def test_area_light_sample_table_equals_oracle(crt):
+    """the fixed draws of the area lights (include/crt.h: crt_area_table) are the oracle's, bit for bit, and lie
+    on the unit disk"""
+    a, b = crt.area_table(), orc.area_table()
+    assert a.tobytes() == b.tobytes()
+    assert (a[:, 0] >= 0).all() and (a[:, 0] < 1).all()
+    assert np.allclose(a[:, 1] ** 2 + a[:, 2] ** 2, 1, atol=1e-6)
+    assert len(np.unique(a[:, 0])) > 1000
+
+
 def test_tiles_partition_the_frame(crt):
     for (w, h, r) in ((720, 360, 1), (1920, 1080, 8), (333, 205, 3), (3840, 2160, 8)):
         total = 0

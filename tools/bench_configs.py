@@ -102,8 +102,29 @@ def soup_8k_one_rank(nranks=8, spp=16):
     ctx.close()
 
 
+def area_lights(samples=30):
+    """soft shadows multiply the shadow rays: one area light x `samples` on the bench scene."""
+    prims = crt.scene_soup(1000000, seed=1)
+    cam, tgt = crt.default_camera()
+    lights = np.zeros(2, crt.LIGHT_DTYPE)
+    lights[0] = crt.default_lights()[0]
+    lights[1]["area"] = 1; lights[1]["position"] = (0, 190, 100); lights[1]["radius"] = 60; lights[1]["color"] = (.8, .8, .8)
+    ctx = crt.Context(0); ctx.set_scene(prims); ctx.set_lights(lights); ctx.build(0)
+    for w, h, b in ((1920, 1080, 2), (3840, 2160, 2)):
+        p = crt.default_params(width=w, height=h, bounces=b, area_samples=samples)
+        ms, rays = timed_frames(ctx, cam, tgt, p, 3)
+        st = ctx.stats()
+        print(json.dumps({"config": f"area light x {samples} samples + 1 directional light, 1M-triangle soup, {w}x{h}, bounces={b}",
+                          "frame_ms_device": round(ms, 3), "rays_per_frame": rays, "rays_shadow": st["rays_shadow"],
+                          "mrays_per_s": round(rays / ms / 1e3, 1), "ms_trace": round(st["ms_trace"], 3),
+                          "ms_shade_resolve": round(st["ms_shade"], 3)}), flush=True)
+    ctx.close()
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["0", "1", "2", "2big", "4"]
+    which = sys.argv[1:] or ["0", "1", "2", "2big", "4", "area"]
+    if "area" in which:
+        area_lights()
     if "0" in which:
         teapot(720, 360, 1, "configs[0]: teapot3.obj + sphere, 720x360, bounces=1 (no reflection)", (1, 16))
     if "1" in which:
