@@ -1,0 +1,140 @@
+"""GPU parity on inputs that stress the compressed 8-wide tree and the padded slab test rather than the shading:
+scenes far smaller / larger / further from the origin than the reference's room, primitives of very different sizes
+in one scene, degenerate triangles, rays from far away.  The oracle's traversal (Ray.cu:184-236 restated) is the
+checker; ids must be equal, t within 1e-4 relative (tests/test_gpu_parity.py states the bar).
+
+Spheres are left out of the shifted / far-origin cases on purpose: intersectSphere evaluates
+c.c + o.o - 2 c.o - r^2 (Ray.cu:110-113), which cancels catastrophically once |c| or |o| is >> r (at 5e4 units one
+ulp of c.c is 256 r^2-units), so it reports hits at meaningless t for rays that come nowhere near the sphere.  The
+brute-force loop over all primitives then "hits" the sphere for 0.2-10 % of such rays, the reference's BVH only where
+the ray also crosses the sphere's 64-primitive leaf box, and a tighter tree where it crosses the sphere's own box:
+three different answers, none of them geometry (tools/exp/g3_probe.py measures them).  Within the reference's room
+(|coordinates| <= 300) the expression is well conditioned and spheres are compared everywhere else in the suite.
+"""
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+T_RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def crt():
+    import cudaraytracer_amd as m
+    return m
+
+
+def rays_at(rng, n, centre, extent):
+    o = (centre + rng.uniform(-3, 3, (n, 3)) * extent).astype(np.float32)
+    tgt = (centre + rng.uniform(-1, 1, (n, 3)) * extent).astype(np.float32)
+    d = (tgt - o).astype(np.float64)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.concatenate([o, d.astype(np.float32)], axis=1)
+
+
+def compare(crt, prims, rays, what, modes=(0, 2), min_hits=100):
+    sc = orc.Scene(prims); sc.build()
+    ids_o, ts_o = sc.trace(rays, nthreads=16)
+    sc.close()
+    assert (ids_o >= 0).sum() >= min_hits, f"{what}: the test rays hit too little ({(ids_o >= 0).sum()})"
+    for mode in modes:
+        ctx = crt.Context(0)
+        try:
+            ctx.set_scene(prims); ctx.build(mode)
+            ids_g, ts_g = ctx.trace(rays)
+        finally:
+            ctx.close()
+        bad = ids_g != ids_o
+        hit = (ids_o >= 0) & ~bad
+        rel = np.abs(ts_g[hit] - ts_o[hit]) / np.maximum(np.abs(ts_o[hit]), 1e-30)
+        print(f"{what} mode={mode}: rays={len(rays)} hits={int((ids_o >= 0).sum())} id_mismatch={int(bad.sum())} "
+              f"t_exact={int((ts_g[hit] == ts_o[hit]).sum())}/{int(hit.sum())}")
+        # the device build (mode 2) has no reference-order pass: exact-t ties may resolve differently there
+        assert bad.sum() <= (2 if mode != 2 else max(2, len(rays) // 5000)), f"{what} mode={mode}: {int(bad.sum())} id mismatches"
+        assert (rel > T_RTOL).sum() == 0
+
+
+def transform(prims, scale, shift):
+    p = prims.copy()
+    for f in ("position", "v1", "v2", "v3"):
+        p[f] = (p[f].astype(np.float64) * scale + np.asarray(shift)).astype(np.float32)
+    p["radius"] = (p["radius"] * scale).astype(np.float32)
+    return p
+
+
+@pytest.mark.parametrize("scale,shift", [(1e-3, (0, 0, 0)), (1e3, (0, 0, 0)), (1.0, (5e4, -3e4, 2e4)), (1e-2, (900.0, 900.0, 900.0))])
+def test_scaled_and_shifted_scenes(crt, scale, shift):
+    prims = transform(crt.scene_teapot(with_sphere=(shift == (0, 0, 0))), scale, shift)
+    rng = np.random.default_rng(5)
+    rays = rays_at(rng, 60000, np.asarray(shift, np.float64) + np.array([0, 20, 0]) * scale, 60 * scale)
+    compare(crt, prims, rays, f"teapot x{scale:g} + {shift}", min_hits=5000)
+
+
+def test_primitives_of_very_different_sizes(crt):
+    """a few huge triangles and spheres among thousands of tiny ones: one node's children span many octaves"""
+    rng = np.random.default_rng(9)
+    small = crt.scene_soup(20000, seed=3)
+    for f in ("v1", "v2", "v3"):
+        small[f] = (small[f] * np.float32(0.02)).astype(np.float32)          # soup shrunk into a 7 x 7 x 10 box
+    big = crt.scene_soup(6, seed=4)
+    c = big["v1"].copy()
+    big["v1"] = c + rng.uniform(-900, 900, (6, 3)).astype(np.float32)
+    big["v2"] = c + rng.uniform(-900, 900, (6, 3)).astype(np.float32)
+    big["v3"] = c + rng.uniform(-900, 900, (6, 3)).astype(np.float32)
+    sph = crt.scene_spheres(40, seed=2)
+    sph["radius"][:3] = (150, 0.01, 40)
+    prims = np.concatenate([big, small, sph])
+    rays = np.concatenate([rays_at(rng, 40000, np.zeros(3), 5.0), rays_at(rng, 40000, np.zeros(3), 200.0)])
+    compare(crt, prims, rays, "mixed sizes", min_hits=20000)
+
+
+def test_degenerate_triangles_never_hit(crt):
+    """zero-area triangles (Ng = normalize(0) = NaN, Ray.cu:145) are never hit, on either side, and do not
+    disturb their neighbours"""
+    prims = crt.scene_soup(5000, seed=6)
+    prims["v2"][::3] = prims["v1"][::3]                       # an edge collapsed
+    prims["v3"][1::7] = prims["v1"][1::7]; prims["v2"][1::7] = prims["v1"][1::7]    # a point
+    rng = np.random.default_rng(2)
+    rays = rays_at(rng, 80000, np.array([0, 0, -40.0]), 150.0)
+    sc = orc.Scene(prims); sc.build()
+    ids_o, _ = sc.trace(rays, nthreads=16); sc.close()
+    degenerate = np.zeros(len(prims), bool); degenerate[::3] = True; degenerate[1::7] = True
+    assert not degenerate[ids_o[ids_o >= 0]].any()
+    compare(crt, prims, rays, "degenerate triangles", min_hits=300)
+
+
+@pytest.mark.parametrize("with_sphere,far_exp", [(False, 5.5), (True, 3.0)])
+def test_rays_from_far_away_and_axis_parallel(crt, with_sphere, far_exp):
+    prims = crt.scene_teapot(with_sphere=with_sphere)
+    rng = np.random.default_rng(12)
+    n = 30000
+    tgt = rng.uniform(-40, 40, (n, 3))
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    dist = 10.0 ** rng.uniform(2, far_exp, (n, 1))            # origins 1e2 .. 3e5 units away (1e3 with the sphere)
+    o = tgt - d * dist
+    far = np.concatenate([o, d], axis=1).astype(np.float32)
+    ax = np.zeros((6000, 6), np.float32)
+    ax[:, :3] = rng.uniform(-45, 45, (6000, 3))
+    ax[:2000, 1] = 300; ax[:2000, 4] = -1                    # straight down
+    ax[2000:4000, 0] = -300; ax[2000:4000, 3] = 1            # +x
+    ax[4000:, 2] = 300; ax[4000:, 5] = -1                    # -z
+    compare(crt, prims, np.concatenate([far, ax]), "far origins + axis-parallel", modes=(0, 1, 2), min_hits=3000)
+
+
+def test_empty_scene_renders_the_room(crt):
+    """no objects at all: every ray falls through to wallIntersection (Ray.cu:513-525)"""
+    prims = np.zeros(0, crt.PRIM_DTYPE)
+    lights = crt.default_lights(); cam, tgt = crt.default_camera()
+    sc = orc.Scene(prims); sc.build()
+    o = sc.render(lights, cam, tgt, 160, 90, 2, nthreads=4)
+    sc.close()
+    for mode in (0, 1, 2):
+        ctx = crt.Context(0)
+        try:
+            ctx.set_scene(prims); ctx.set_lights(lights); ctx.build(mode)
+            g = ctx.render(cam, tgt, crt.default_params(width=160, height=90, bounces=2))
+        finally:
+            ctx.close()
+        assert np.abs(g.astype(int) - o["bgr"].astype(int)).max() <= 1, f"mode {mode}"
