@@ -26,6 +26,7 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+VALU_ISSUE_PEAK_G = 256 * 4 * 2.4 / 4    # 256 CUs x 4 SIMDs, one 64-wide VALU instruction per SIMD per 4 clocks, 2.4 GHz
 _T0 = time.perf_counter()
 
 
@@ -222,11 +223,14 @@ def main():
         # HBM-side bytes per launch of the same kernel from the committed PMC passes (rocprofv3 cannot be
         # nested inside this process): only quoted for the default workload those passes measured
         traffic = None
+        valu_instr = None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
         default_workload = (a.tris, a.width, a.height, a.bounces, a.spp, a.bvh, world) == (1000000, 3840, 2160, 3, 1, 0, 1)
         if default_workload and os.path.exists(tpath):
             try:
-                traffic = float(json.load(open(tpath))["hbm_bytes_per_launch"])
+                tj = json.load(open(tpath))
+                traffic = float(tj["hbm_bytes_per_launch"])
+                valu_instr = tj.get("valu_wave_instructions_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -261,6 +265,11 @@ def main():
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
+                # what actually binds this kernel: VALU wave-instructions per launch from the committed
+                # SQ_INSTS_VALU pass over this launch duration, against one issue per SIMD per 4 clocks at 2.4 GHz
+                "valu_issue": ({"achieved": round(valu_instr / (avg_ms * 1e-3) / 1e9, 1), "peak": VALU_ISSUE_PEAK_G,
+                                "unit": "G wave-instructions/s", "frac": round(valu_instr / (avg_ms * 1e-3) / 1e9 / VALU_ISSUE_PEAK_G, 4)}
+                               if valu_instr and avg_ms > 0 else None),
                 "algorithmic_bytes_per_launch": int(per_launch_bytes), "avg_launch_ms": round(avg_ms, 4),
                 "launches_timed": launches,
                 "per_ray": {"node_visits": round(cst["node_visits"] / max(1, n_near), 2),

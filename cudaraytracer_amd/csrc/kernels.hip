@@ -460,7 +460,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
     int found = 0;
     uint32_t lkind = kShadowDirectional;   /* shadow lanes: float bits of the ray's light distance (kernels.h) */
     unsigned long long nbox[2] = {0, 0}, ntri[2] = {0, 0}, nsph[2] = {0, 0}, nvis[2] = {0, 0};      /* [0] nearest-hit rays, [1] shadow rays */
-    unsigned long long sch[5] = {0, 0, 0, 0, 0}, nzero = 0;
+    unsigned long long sch[5] = {0, 0, 0, 0, 0}, nzero = 0, nstale = 0, nfound = 0;
 
     for (;;) {
         /* ---- refill, first half: when enough lanes are idle, take rays off the queue and ISSUE their
@@ -583,7 +583,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
 #undef PAIR23
                         const uint32_t vmask = h1.x >> 24, imask = em >> 24;
                         raw &= vmask;                       /* an empty slot can pass the padded test of a degenerate node */
-                        if (COUNT) { nbox[ray >> 31] += (unsigned long long)__popc(vmask); nvis[ray >> 31]++; if (raw == 0u) nzero++; }
+                        if (COUNT) { nbox[ray >> 31] += (unsigned long long)__popc(vmask); nvis[ray >> 31]++; if (raw == 0u) nzero++; if ((ray >> 31) && found) nstale++; }
                         gbase = h1.x & 0xffffffu;
                         gmask = (imask << 8) | (uint32_t)s_perm[R][raw & imask];
                         plm = h1.y | ((raw & ~imask) << 24);
@@ -615,7 +615,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                                 if (t < tbest) { tbest = t; best = (int)p; }
                             } else {
                                 if (!(t > 0.000000001f)) { found = 0; finish = true; }
-                                else { found = 1; if (tbest > 0.000000001f) tbest = 0.000000001f; }
+                                else { if (COUNT && !found) nfound++; found = 1; if (tbest > 0.000000001f) tbest = 0.000000001f; }
                             }
                         }
                     }
@@ -690,6 +690,8 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
         }
         if (lane == 0) for (int i = 0; i < 5; i++) atomicAdd(&A.counters[8 + i], sch[i]);
         atomicAdd(&A.counters[13], nzero);
+        atomicAdd(&A.counters[14], nstale);      /* node visits of shadow rays that already hold a hit with t > 1e-9 */
+        atomicAdd(&A.counters[15], nfound);
     }
 }
 
