@@ -612,7 +612,30 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                             if (t < tbest || (t == tbest && best >= 0 && A.sv.rank[p] < A.sv.rank[best])) { tbest = t; best = (int)p; }
                         } else {
                             if (lkind != kShadowDirectional) {
-                                if (t < tbest) { tbest = t; best = (int)p; }
+                                /* point light / area sample: the reference takes the nearest hit t0 and calls the point
+                                 * shadowed iff dtoLight > |(o + t0 d) - o| (Ray.cu:625-629; area samples also need
+                                 * t0 > 1e-9, Ray.cu:589).  Any hit t >= t0 that lies before the light by a margin far
+                                 * above the rounding of that expression decides the same without knowing t0 */
+                                const bool area = (lkind >> 31) != 0u;
+                                if (found) {                  /* area sample known to be occluded: only a hit at t <= 1e-9 lights it */
+                                    if (!(t > 0.000000001f)) { found = 0; best = -1; finish = true; }
+                                } else {
+                                    if (t < tbest) { tbest = t; best = (int)p; }
+                                    if (area && !(t > 0.000000001f)) { best = -1; finish = true; }     /* t0 <= 1e-9: lit */
+                                    else {
+                                        const vec3 ip = o + t * d;
+                                        const float gx = ip.x - o.x, gy = ip.y - o.y, gz = ip.z - o.z;
+                                        /* |(o + t0 d) - o| for any t0 in [-1e-4, t] is below this bound: relative slack for |d| and the
+                                         * square root, absolute slack for the rounding of o + t d (a few ulp of |o| + t) and for t0 < 0 */
+                                        const float slack = 2e-6f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z)) + 2e-4f;
+                                        if (sqrtf(gx * gx + gy * gy + gz * gz) * 1.00001f + slack < __uint_as_float(lkind & 0x7fffffffu)) {
+                                            if (COUNT) nfound++;
+                                            found = 1;
+                                            if (area) { if (tbest > 0.000000001f) tbest = 0.000000001f; }
+                                            else finish = true;
+                                        }
+                                    }
+                                }
                             } else {
                                 if (!(t > 0.000000001f)) { found = 0; finish = true; }
                                 else { if (COUNT && !found) nfound++; found = 1; if (tbest > 0.000000001f) tbest = 0.000000001f; }
@@ -628,7 +651,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                     A.hitT[ray] = tbest;
                 } else {
                     bool shadowed;
-                    if (lkind != kShadowDirectional) {
+                    if (lkind != kShadowDirectional && !found) {
                         shadowed = false;
                         if (best >= 0) {
                             /* Ray.cu:625-629; k_shade computed dtoLight from this very origin */
@@ -974,7 +997,15 @@ __constant__ WallDef c_walls[6] = {
     {{0, -1, 0}, {0, 200.0f, 0}, 0, {0.9f, 0.9f, 0.9f}, {1.0f, 1.0f, 1.0f}},
 };
 
-__global__ __launch_bounds__(256) void k_shade(FrameParams P, FrameBuffers B, SceneView sv, LightsParam LP,
+#ifndef CRT_SHADE_MIN_WAVES
+#define CRT_SHADE_MIN_WAVES 4          /* 128 VGPRs (28 bytes of spill) instead of 131: 4 waves per SIMD, shade+resolve 1.87 -> 1.67 ms per frame; 5 and 6 spill too much */
+#endif
+#if CRT_SHADE_MIN_WAVES > 0
+#define CRT_SHADE_BOUNDS __launch_bounds__(256, CRT_SHADE_MIN_WAVES)
+#else
+#define CRT_SHADE_BOUNDS __launch_bounds__(256)
+#endif
+__global__ CRT_SHADE_BOUNDS void k_shade(FrameParams P, FrameBuffers B, SceneView sv, LightsParam LP,
                                                 const uint32_t* count, uint32_t* next_count, uint32_t* shadow_count) {
     /* queue appends are reserved once per BLOCK iteration (LDS partial sums + one atomic per
      * queue): per-wave atomics on the two counters made this kernel atomic-bound */

@@ -10,6 +10,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-ma
 rm -f $O/kernels.o
 /opt/rocm/bin/hipcc $FLAGS -c kernels.hip -o $O/kernels.o -Rpass-analysis=kernel-resource-usage > $O/kernels.log 2>&1 || { grep -A6 error $O/kernels.log; exit 1; }
 grep -A12 "k_trace8ILi0ELb0" $O/kernels.log | grep -E "VGPRs:|ScratchSize|Occupancy|LDS Size" | sed 's/.*remark: [^ ]* *//' | tr '\n' ' '; echo
+/opt/rocm/bin/hipcc $FLAGS -c lbvh.hip -o $O/lbvh.o
 for f in crt_api bvh_build scene; do /opt/rocm/bin/hipcc $FLAGS -c $f.cpp -o $O/$f.o; done
 /opt/rocm/bin/hipcc $FLAGS -c compat/compat.cpp -o $O/compat.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build_variants/libcrt_$NAME.so $O/*.o
