@@ -1007,7 +1007,11 @@ int crt_blob_import_device(crt_ctx* c, const void* dev_ptr, size_t bytes) {
         }
         HIPCHECK(c, hipMemcpy(c->d_blob, dev_ptr, bytes, hipMemcpyDeviceToDevice));
     }
-    c->blob_bytes = bytes; c->hdr = h; c->built = true; c->imported = (dev_ptr != c->d_blob) || c->prims.empty();
+    /* a context that was given the same scene with crt_scene_set before the import (every rank of an animated
+     * multi-GPU run) keeps its crt_prim array and material ids, so crt_animate_device / crt_scene_update /
+     * crt_bvh_refit / crt_bvh_build work on it as on the rank that built the blob */
+    c->blob_bytes = bytes; c->hdr = h; c->built = true; c->imported = c->prims.size() != (size_t)h.nprims;
+    c->have_ref = c->have_ref && dev_ptr == c->d_blob;
     int rc = ensure(c, c->d_arrive, c->arrive_cap, (size_t)h.nnodes + 1);
     if (rc) return rc;
     scene_abs_from_box(c);

@@ -93,9 +93,29 @@ class ShardedRenderer:
         self.gathered = None
         self.sizes = None
 
-    def broadcast_scene(self, prims=None, lights=None, mode=0):
-        """Rank 0 builds; everyone ends with the same packed scene + BVH resident in its HBM."""
+    def _bcast_bytes(self, payload):
+        """broadcast a bytes-like object from rank 0 (device tensors: RCCL has no host path)"""
         torch, dist = self.torch, self.dist
+        n = torch.tensor([len(payload) if self.rank == 0 else 0], dtype=torch.int64, device=self.dev)
+        dist.broadcast(n, 0)
+        if self.rank == 0:
+            buf = torch.from_numpy(np.frombuffer(payload, np.uint8).copy()).to(self.dev)
+        else:
+            buf = torch.empty(int(n.item()), dtype=torch.uint8, device=self.dev)
+        dist.broadcast(buf, 0)
+        return buf.cpu().numpy().tobytes()
+
+    def broadcast_scene(self, prims=None, lights=None, mode=0, animated=False):
+        """Rank 0 builds; everyone ends with the same packed scene + BVH resident in its HBM.
+
+        animated=True also hands every rank the crt_prim array (SURVEY 8(e) collective (2)), so that animate()
+        can advance the scene on every rank without further communication."""
+        torch, dist = self.torch, self.dist
+        self.animated = animated
+        if animated:
+            raw = self._bcast_bytes(np.ascontiguousarray(prims, api.PRIM_DTYPE).tobytes() if self.rank == 0 else b"")
+            if self.rank != 0:
+                self.ctx.set_scene(np.frombuffer(raw, api.PRIM_DTYPE).copy())
         if self.rank == 0:
             self.ctx.set_scene(prims)
             self.ctx.build(mode)
@@ -122,6 +142,18 @@ class ShardedRenderer:
         dist.broadcast(lb, 0)
         self.ctx.set_lights(np.frombuffer(lb.cpu().numpy().tobytes(), api.LIGHT_DTYPE))
         return nbytes
+
+    def animate(self, rebuild=False, grow_only=False):
+        """One step of the reference's animation (main.cu:545-573) on every rank: the step is deterministic, so the
+        ranks replicate it on their own copy of the scene instead of exchanging moved primitives; then a refit, or
+        (rebuild=True, the "every 20th frame" of main.cu:534-541) a rebuild on the device.  No collective."""
+        if not getattr(self, "animated", False):
+            raise RuntimeError("broadcast_scene(..., animated=True) first: the other ranks hold no crt_prim array")
+        self.ctx.animate_device()
+        if rebuild:
+            self.ctx.build(2)          # CRT_BVH_WIDE_DEVICE
+        else:
+            self.ctx.refit(grow_only)
 
     def _ensure(self, params):
         torch = self.torch

@@ -166,7 +166,10 @@ int crt_trace_shadow(crt_ctx*, const float* org_dir, int n, uint8_t* shadowed_ou
  *      broadcasts (RCCL) and imports on the other ranks ---- */
 int crt_blob_size(crt_ctx*, size_t* bytes);
 int crt_blob_device_ptr(crt_ctx*, void** dev_ptr);
-int crt_blob_import_device(crt_ctx*, const void* dev_ptr, size_t bytes);   /* copies; D2D */
+/* copies (D2D).  A context that already holds the SAME scene (crt_scene_set with the primitives the blob was built
+ * from, e.g. every rank of an animated multi-GPU run) stays a full context afterwards: crt_animate_device,
+ * crt_scene_update, crt_bvh_refit and crt_bvh_build work on it.  Without a scene the import is render-only. */
+int crt_blob_import_device(crt_ctx*, const void* dev_ptr, size_t bytes);
 int crt_tile_owner(int tile_index, int nranks);
 /* number of tiles this rank owns and their pixel count; tile list in owned order */
 int crt_tiles_owned(const crt_params*, int32_t* ntiles, int64_t* npixels, int32_t* tile_ids, int cap);

@@ -14,15 +14,21 @@ from cudaraytracer_amd.parallel import ShardedRenderer  # noqa: E402
 
 def main():
     out, w, h, bounces, mode = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    frames = int(sys.argv[6]) if len(sys.argv) > 6 else 0          # animation steps before the frame that is saved
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
     sr = ShardedRenderer(dist, torch, rank, world, 0)
     prims = np.concatenate([crt.scene_teapot(with_sphere=True), crt.scene_soup(5000, seed=6)]) if rank == 0 else None
-    sr.broadcast_scene(prims, crt.default_lights() if rank == 0 else None, mode)
+    if frames and rank == 0:
+        prims = np.concatenate([prims, crt.scene_spheres(200, seed=8)])
+    sr.broadcast_scene(prims, crt.default_lights() if rank == 0 else None, mode, animated=frames > 0)
     cam, tgt = crt.default_camera()
     p = crt.default_params(width=w, height=h, bounces=bounces)
     for _ in range(2):                                   # twice: buffers and tile lists are reused
+        frame = sr.render(cam, tgt, p)
+    for f in range(1, frames + 1):                       # replicated animation: refit, every 4th step a device rebuild
+        sr.animate(rebuild=(f % 4 == 0))
         frame = sr.render(cam, tgt, p)
     if rank == 0:
         np.save(out, frame.cpu().numpy().reshape(h, w, 3))

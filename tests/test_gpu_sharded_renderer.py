@@ -30,3 +30,36 @@ def test_sharded_renderer_gathers_the_single_gpu_frame(tmp_path, world, mode):
     finally:
         ctx.close()
     assert np.array_equal(np.load(out), full)
+
+
+def test_sharded_renderer_animates_on_every_rank(tmp_path):
+    """SURVEY 8(e) collective (2): the ranks replicate the deterministic animation step (crt_animate_device) on the
+    scene they were handed once, refit locally, rebuild on the device every 4th step; the gathered frame after 6
+    steps equals one GPU doing the same."""
+    import cudaraytracer_amd as crt
+    world, mode, w, h, bounces, frames = 2, 0, 300, 200, 2, 6
+    out = str(tmp_path / "anim.npy")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), out, str(w), str(h), str(bounces), str(mode), str(frames)],
+                              env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    logs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    prims = np.concatenate([crt.scene_teapot(with_sphere=True), crt.scene_soup(5000, seed=6), crt.scene_spheres(200, seed=8)])
+    ctx = crt.Context(0)
+    ctx.set_scene(prims); ctx.set_lights(crt.default_lights()); ctx.build(mode)
+    cam, tgt = crt.default_camera()
+    try:
+        for f in range(1, frames + 1):
+            ctx.animate_device()
+            if f % 4 == 0:
+                ctx.build(2)
+            else:
+                ctx.refit(False)
+        full = ctx.render(cam, tgt, crt.default_params(width=w, height=h, bounces=bounces))
+        still = crt.Context(0)
+        still.set_scene(prims); still.set_lights(crt.default_lights()); still.build(mode)
+        assert not np.array_equal(full, still.render(cam, tgt, crt.default_params(width=w, height=h, bounces=bounces)))
+        still.close()
+    finally:
+        ctx.close()
+    assert np.array_equal(np.load(out), full)
