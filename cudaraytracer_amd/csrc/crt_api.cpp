@@ -509,10 +509,16 @@ int crt_bvh_build(crt_ctx* c, int mode) {
         c->host_stale = false;
     }
     auto t0 = std::chrono::steady_clock::now();
+    /* the reference's own split (its leaf order is the tie-break rank).  It does not terminate when more than 64
+     * primitives share a centroid coordinate on the axis it picks (bvh.cu:12-273 would recurse forever): the
+     * reference topology then cannot be built at all; the wide tree is built without it and exact-t ties
+     * resolve by scene index, as they do for the device build */
     int rc = build_reference_tree(c->prims.data(), n, c->ref);
-    if (rc) return fail(c, rc, "BVH build: reference split does not terminate (more than 64 primitives share a centroid)");
-    c->have_ref = true;
-    if (mode == CRT_BVH_WIDE) rc = build_wide(c->prims.data(), n, &c->ref, c->bvh);
+    c->have_ref = rc == 0;
+    if (rc && mode == CRT_BVH_REFERENCE)
+        return fail(c, rc, "BVH build: the reference's split does not terminate on this scene (more than 64 primitives share a centroid "
+                           "coordinate on the split axis); use CRT_BVH_WIDE or CRT_BVH_WIDE_DEVICE");
+    if (mode == CRT_BVH_WIDE) rc = build_wide(c->prims.data(), n, c->have_ref ? &c->ref : nullptr, c->bvh);
     else rc = pack_reference(c->prims.data(), n, c->ref, c->bvh);
     if (rc) return fail(c, rc, "BVH build failed");
     auto t1 = std::chrono::steady_clock::now();
@@ -604,7 +610,7 @@ int crt_bvh_free(crt_ctx* c) {
 
 int crt_bvh_reference_order(crt_ctx* c, int32_t* rank_out, int n) {
     if (!c || !rank_out) return CRT_ERR_ARG;
-    if (!c->have_ref) return fail(c, CRT_ERR_STATE, "crt_bvh_reference_order: no BVH");
+    if (!c->have_ref) return fail(c, CRT_ERR_STATE, "crt_bvh_reference_order: no reference order (no host build yet, a device build, or a scene on which the reference's split does not terminate)");
     if ((size_t)n != c->prims.size()) return fail(c, CRT_ERR_ARG, "crt_bvh_reference_order: n differs from the scene size");
     for (int i = 0; i < n; i++) rank_out[c->ref.order[i]] = i;
     return CRT_OK;
@@ -1077,8 +1083,8 @@ int crt_host_bvh(const crt_prim* prims, int n, int mode, int32_t* nnodes, int32_
     if (mode != CRT_BVH_WIDE && mode != CRT_BVH_REFERENCE) return CRT_ERR_ARG;
     RefTree ref; HostBVH bvh;
     int rc = build_reference_tree(prims, n, ref);
-    if (rc) return rc;
-    rc = mode == CRT_BVH_WIDE ? build_wide(prims, n, &ref, bvh) : pack_reference(prims, n, ref, bvh);
+    if (rc && mode == CRT_BVH_REFERENCE) return rc;
+    rc = mode == CRT_BVH_WIDE ? build_wide(prims, n, rc ? nullptr : &ref, bvh) : pack_reference(prims, n, ref, bvh);
     if (rc) return rc;
     *nnodes = (int32_t)bvh.node_count();
     if (depth) *depth = bvh.depth;

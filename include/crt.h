@@ -123,8 +123,13 @@ int crt_scene_get(crt_ctx*, crt_prim* prims_out, int n);        /* current scene
 
 /* ---- BVH: replaces newBuild+constructTree (main.cu:33-136, bvh.cu:12-273), refitTree
  *      (bvh.cu:288-400) and freeTree (bvh.cu:274-286) ---- */
-#define CRT_BVH_WIDE 0       /* binned-SAH tree collapsed to compressed 8-wide nodes, <=4 primitives per leaf */
-#define CRT_BVH_REFERENCE 1  /* the reference's topology (mean-centroid split, <=64 per leaf), exact boxes */
+#define CRT_BVH_WIDE 0       /* binned-SAH tree collapsed to compressed 8-wide nodes, <=4 primitives per leaf.  Exact-t ties
+                              * resolve by the reference's leaf order; on scenes where the reference's split does not
+                              * terminate (below) the tree is still built and ties resolve by scene index */
+#define CRT_BVH_REFERENCE 1  /* the reference's topology (mean-centroid split, <=64 per leaf), exact boxes.  CRT_ERR_BUILD where
+                              * constructTree would recurse forever: more than 64 primitives sharing a centroid coordinate
+                              * on the axis it picks (its box maxima never fall below 0, main.cu:35, so that axis can be one
+                              * along which a flat group has no extent at all) */
 #define CRT_BVH_WIDE_DEVICE 2 /* the same 8-wide format built on the device (Morton-order linear BVH, one primitive per leaf):
                               * milliseconds instead of a second for 1M primitives, for "rebuild every N frames" on large
                               * animated scenes.  Builds from the device copy of the scene (after crt_animate_device no

@@ -138,3 +138,27 @@ def test_empty_scene_renders_the_room(crt):
         finally:
             ctx.close()
         assert np.abs(g.astype(int) - o["bgr"].astype(int)).max() <= 1, f"mode {mode}"
+
+
+def test_scene_the_reference_cannot_build(crt):
+    """64 teapots below y = 0 send constructTree into endless recursion (tests/test_host_layer.py explains why); the
+    default and the device build still render it.  The checker is the oracle's loop over all primitives."""
+    from test_host_layer import teapot_grid
+    prims = teapot_grid(crt)
+    rng = np.random.default_rng(21)
+    rays = rays_at(rng, 50000, np.array([0.0, -40.0, 0.0]), 120.0)
+    sc = orc.Scene(prims)
+    ids_o, ts_o = sc.trace_brute(rays, nthreads=16)
+    sc.close()
+    assert (ids_o >= 0).sum() > 5000
+    for mode in (0, 2):
+        ctx = crt.Context(0)
+        try:
+            ctx.set_scene(prims); ctx.build(mode)
+            ids_g, ts_g = ctx.trace(rays)
+            with pytest.raises(crt.CrtError):
+                ctx.build(1)
+        finally:
+            ctx.close()
+        # ties in t (shared edges of the mesh) resolve by scene index on both sides
+        assert np.array_equal(ids_g, ids_o) and np.array_equal(ts_g, ts_o), f"mode {mode}: {(ids_g != ids_o).sum()} ids differ"

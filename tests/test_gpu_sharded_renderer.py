@@ -19,7 +19,7 @@ def test_sharded_renderer_gathers_the_single_gpu_frame(tmp_path, world, mode):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29530 + world), WORLD_SIZE=str(world))
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), out, str(w), str(h), str(bounces), str(mode)],
                               env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
-    logs = [p.communicate(timeout=240)[0] for p in procs]
+    logs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
     prims = np.concatenate([crt.scene_teapot(with_sphere=True), crt.scene_soup(5000, seed=6)])
     ctx = crt.Context(0)
@@ -42,7 +42,7 @@ def test_sharded_renderer_animates_on_every_rank(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE=str(world))
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), out, str(w), str(h), str(bounces), str(mode), str(frames)],
                               env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
-    logs = [p.communicate(timeout=240)[0] for p in procs]
+    logs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
     prims = np.concatenate([crt.scene_teapot(with_sphere=True), crt.scene_soup(5000, seed=6), crt.scene_spheres(200, seed=8)])
     ctx = crt.Context(0)

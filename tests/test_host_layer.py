@@ -122,8 +122,7 @@ def test_reference_topology_equals_oracle_tree(crt, scene):
         rec(0, h["root"], 0)
 
 
-def test_wide_bvh_is_a_valid_hierarchy(crt):
-    prims = np.concatenate([crt.scene_soup(6000, seed=3), crt.scene_spheres(500, seed=3)])
+def check_wide_hierarchy(crt, prims):
     h = crt.host_bvh(prims, 0)
     boxes, links, s2s = h["boxes"], h["links"], h["slot_to_scene"]
     assert sorted(s2s.tolist()) == list(range(len(prims)))                 # every primitive in exactly one leaf
@@ -155,6 +154,11 @@ def test_wide_bvh_is_a_valid_hierarchy(crt):
                 assert tuple(h["parents"][link]) == (node, k)
                 stack.append((link, b, depth + 1))
     assert seen.all() and depth_seen == h["depth"]
+    return h
+
+
+def test_wide_bvh_is_a_valid_hierarchy(crt):
+    check_wide_hierarchy(crt, np.concatenate([crt.scene_soup(6000, seed=3), crt.scene_spheres(500, seed=3)]))
 
 
 def test_coincident_centroids_do_not_hang(crt):
@@ -165,6 +169,34 @@ def test_coincident_centroids_do_not_hang(crt):
     with pytest.raises(crt.CrtError) as e:
         crt.host_bvh(prims, 1)
     assert e.value.code == -6
+    h = check_wide_hierarchy(crt, prims)
+    assert np.array_equal(h["rank_of_scene"], np.arange(100))       # no reference order: ties resolve by scene index
+
+
+def teapot_grid(crt):
+    """64 small teapots below y = 0: the reference's box maxima never fall below 0 (main.cu:35), so for a group of
+    neighbouring teapots y looks like the longest axis, and the flat rings of the mesh (hundreds of triangles with
+    one centroid y) can never be split: constructTree recurses forever on this perfectly ordinary scene."""
+    tp = crt.scene_teapot(with_sphere=False)
+    grid = []
+    for i in range(8):
+        for j in range(8):
+            q = tp.copy()
+            for f in ("v1", "v2", "v3"):
+                q[f] = (q[f] * np.float32(0.4) + np.array([(i - 3.5) * 45, -100 + (j % 3) * 60, (j - 3.5) * 60], np.float32)).astype(np.float32)
+            grid.append(q)
+    return np.concatenate(grid)
+
+
+def test_scene_the_reference_cannot_build(crt):
+    prims = teapot_grid(crt)
+    sc = orc.Scene(prims)
+    with pytest.raises(RuntimeError):
+        sc.build()                                   # the oracle restates the runaway recursion (bounded)
+    sc.close()
+    with pytest.raises(crt.CrtError):
+        crt.host_bvh(prims, 1)
+    check_wide_hierarchy(crt, prims)
 
 
 def test_area_light_sample_table_equals_oracle(crt):
