@@ -17,7 +17,8 @@ extern "C" {
 #endif
 
 #define CRT_MAX_LIGHTS 8
-#define CRT_MAX_PRIMS ((1 << 25) - 64)
+#define CRT_MAX_PRIMS ((1 << 25) - 64)   /* leaf links hold a 25-bit slot; the compressed wide tree (CRT_BVH_WIDE*) holds 24-bit
+                                          * node and slot bases: beyond 2^24 primitives its build returns CRT_ERR_BUILD */
 
 typedef enum crt_status {
     CRT_OK = 0,
