@@ -164,6 +164,14 @@ def test_point_light_and_odd_size(crt, teapot):
     try:
         g, o, p = render_pair(crt, ctx, sc, 333, 205, 3, lights)   # not a multiple of the 32x32 tile
         check_image(g, o, "point light 333x205 bounces=3", max_bad=4)
+        # the same through the reference topology (k_trace<SHADOW> takes the light's distance from the ray record too)
+        ctx1 = crt.Context(0)
+        try:
+            ctx1.set_scene(prims); ctx1.set_lights(lights); ctx1.build(1)
+            g1 = ctx1.render(crt.default_camera()[0], crt.default_camera()[1], p)
+        finally:
+            ctx1.close()
+        check_image(g1, o, "point light 333x205 bounces=3, reference topology", max_bad=4)
     finally:
         ctx.set_lights(crt.default_lights())
         sc.stats(reset=True)
