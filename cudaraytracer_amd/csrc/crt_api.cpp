@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 
 using namespace crt;
 
@@ -64,6 +65,7 @@ struct crt_ctx {
     int32_t* hitSlot = nullptr; float* hitT = nullptr;
     float4 *rc = nullptr, *contrib = nullptr, *shO = nullptr, *shD = nullptr, *accum = nullptr, *sum = nullptr;
     uint8_t* shflag = nullptr;
+    unsigned char* h_stage = nullptr; size_t stage_cap = 0;     /* pinned staging for crt_render's copy to the caller's buffer */
     float4* d_area_table = nullptr;      /* unit-disk samples of the area lights, uploaded on first use */
     uint8_t* d_bgr = nullptr; size_t bgr_cap = 0;
     int32_t* cap_ids = nullptr; float* cap_ts = nullptr; size_t cap_planes = 0; size_t cap_npix = 0;
@@ -336,6 +338,7 @@ void crt_destroy(crt_ctx* c) {
                     c->d_testctr, c->d_ovf, c->d_sortkeys, c->d_sortperm, c->d_sorthist, c->d_sortkeys2, c->d_sortperm2,
                     c->d_lbvh, c->d_lbvh_nodes, c->d_lbvh_s2s, c->d_area_table};
     for (void* p : ptrs) if (p) hipFree(p);
+    if (c->h_stage) hipHostFree(c->h_stage);
     for (uint32_t* q : c->tl_ids) if (q) hipFree(q);
     for (hipEvent_t e : c->evpool) hipEventDestroy(e);
     hipStreamDestroy(c->stream);
@@ -891,7 +894,52 @@ int crt_render(crt_ctx* c, const crt_camera* cam, const crt_params* p, unsigned 
     if (!c || !bgr_out_host) return fail(c, CRT_ERR_ARG, "crt_render: null output buffer");
     int rc = crt_render_device(c, cam, p, nullptr);
     if (rc) return rc;
-    HIPCHECK(c, hipMemcpy(bgr_out_host, c->d_bgr, (size_t)p->width * p->height * 3, hipMemcpyDeviceToHost));
+    const size_t bytes = (size_t)p->width * p->height * 3;
+    /* The caller's buffer is ordinary pageable memory (the reference mallocs it, main.cu:512): a plain hipMemcpy into it
+     * runs at ~7 GB/s.  Frames of a few MB and more go through a pinned staging buffer instead: the device copies it in
+     * chunks at PCIe speed while host threads move finished chunks into the caller's buffer. */
+    constexpr size_t kStageMin = 2u << 20;
+    constexpr int kChunks = 8, kThreads = 4;
+    if (bytes < kStageMin) {
+        HIPCHECK(c, hipMemcpy(bgr_out_host, c->d_bgr, bytes, hipMemcpyDeviceToHost));
+        return CRT_OK;
+    }
+    if (bytes > c->stage_cap || !c->h_stage) {
+        if (c->h_stage) { HIPCHECK(c, hipHostFree(c->h_stage)); c->h_stage = nullptr; c->stage_cap = 0; }
+        if (hipHostMalloc((void**)&c->h_stage, bytes, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            c->h_stage = nullptr;                    /* no pinned memory to be had: the plain copy still works */
+            HIPCHECK(c, hipMemcpy(bgr_out_host, c->d_bgr, bytes, hipMemcpyDeviceToHost));
+            return CRT_OK;
+        }
+        c->stage_cap = bytes;
+    }
+    const size_t chunk = ((bytes + kChunks - 1) / kChunks + 4095) & ~(size_t)4095;
+    hipEvent_t ev[kChunks];
+    int nchunks = 0;
+    for (size_t off = 0; off < bytes; off += chunk, nchunks++) {
+        const size_t len = off + chunk < bytes ? chunk : bytes - off;
+        ev[nchunks] = next_event(c);
+        HIPCHECK(c, hipMemcpyAsync(c->h_stage + off, (const unsigned char*)c->d_bgr + off, len, hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(c, hipEventRecord(ev[nchunks], c->stream));
+    }
+    c->evused -= nchunks;                            /* the events go back to the pool: they are done when this call returns */
+    std::thread workers[kThreads];
+    hipError_t werr[kThreads];
+    for (int t = 0; t < kThreads; t++) {
+        werr[t] = hipSuccess;
+        workers[t] = std::thread([&, t] {
+            (void)hipSetDevice(c->device);
+            for (int k = t; k < nchunks; k += kThreads) {
+                const hipError_t e = hipEventSynchronize(ev[k]);
+                if (e != hipSuccess) { werr[t] = e; return; }
+                const size_t off = (size_t)k * chunk, len = off + chunk < bytes ? chunk : bytes - off;
+                memcpy(bgr_out_host + off, c->h_stage + off, len);
+            }
+        });
+    }
+    for (auto& w : workers) w.join();
+    for (int t = 0; t < kThreads; t++) HIPCHECK(c, werr[t]);
     return CRT_OK;
 }
 
