@@ -42,7 +42,7 @@ class Camera(C.Structure):
 class Params(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("bounces", C.c_int32), ("spp", C.c_int32),
                 ("tile_w", C.c_int32), ("tile_h", C.c_int32), ("rank", C.c_int32), ("nranks", C.c_int32),
-                ("sort_rays", C.c_int32), ("area_samples", C.c_int32), ("reserved", C.c_int32 * 6)]
+                ("sort_rays", C.c_int32), ("area_samples", C.c_int32), ("use_graph", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class Stats(C.Structure):

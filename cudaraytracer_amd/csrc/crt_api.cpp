@@ -65,6 +65,13 @@ struct crt_ctx {
     int32_t* hitSlot = nullptr; float* hitT = nullptr;
     float4 *rc = nullptr, *contrib = nullptr, *shO = nullptr, *shD = nullptr, *accum = nullptr, *sum = nullptr;
     uint8_t* shflag = nullptr;
+    /* crt_params.use_graph: the frame's launch sequence captured once and replayed while nothing but the scene's
+     * contents changes */
+    struct GraphKey {
+        crt_camera cam; crt_params p; LightsParam lights;
+        const void* ptrs[12]; uint32_t nnodes, nprims, mode; int counting, capture, grid; float scene_abs;
+    };
+    GraphKey graph_key{}; hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; bool in_capture = false;
     unsigned char* h_stage = nullptr; size_t stage_cap = 0;     /* pinned staging for crt_render's copy to the caller's buffer */
     float4* d_area_table = nullptr;      /* unit-disk samples of the area lights, uploaded on first use */
     uint8_t* d_bgr = nullptr; size_t bgr_cap = 0;
@@ -210,6 +217,7 @@ hipEvent_t next_event(crt_ctx* c) {
 }
 enum { EV_START = 0, EV_GEN, EV_TRACE_N, EV_SHADE, EV_TRACE_S, EV_RESOLVE, EV_CONVERT, EV_SORT, EV_TRACE_M };
 void mark(crt_ctx* c, int kind) {
+    if (c->in_capture) return;             /* per-kernel timing is not available for a replayed graph */
     hipEvent_t e = next_event(c);
     hipEventRecord(e, c->stream);
     c->evlog.emplace_back(kind, (int)c->evused - 1);
@@ -339,6 +347,8 @@ void crt_destroy(crt_ctx* c) {
                     c->d_lbvh, c->d_lbvh_nodes, c->d_lbvh_s2s, c->d_area_table};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_stage) hipHostFree(c->h_stage);
+    if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
+    if (c->graph) hipGraphDestroy(c->graph);
     for (uint32_t* q : c->tl_ids) if (q) hipFree(q);
     for (hipEvent_t e : c->evpool) hipEventDestroy(e);
     hipStreamDestroy(c->stream);
@@ -757,7 +767,12 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
     }
     c->evused = 0; c->evlog.clear();
     const SceneView sv = view_of(c);
-    mark(c, EV_START);
+    /* the slab-test pad scales with the scene's extent, a kernel argument: a replayed graph keeps the value it was
+     * captured with, so graph mode rounds it up to a power of two (a larger pad is as conservative) and re-captures
+     * only when an animated scene outgrows it */
+    float sabs = c->scene_abs;
+    if (p->use_graph) { int e = 0; (void)frexpf(sabs > 0.f ? sabs : 1.f, &e); sabs = ldexpf(1.0f, e); }
+    auto enqueue = [&]() {
     for (int s = 0; s < spp; s++) {
         uint32_t* ctr = c->d_ctr + (size_t)s * kCtrStride;
         fp.sample = s;
@@ -777,7 +792,7 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
         const bool wide = c->hdr.mode == CRT_BVH_WIDE;
         auto common = [&](TraceArgs& t, int launch) {
             t.sv = sv; t.next = ctr + kCtrFetch0 + launch * 8 * kFetchStride;
-            t.hitSlot = c->hitSlot; t.hitT = c->hitT; t.shflag = c->shflag; t.scene_abs = c->scene_abs;
+            t.hitSlot = c->hitSlot; t.hitT = c->hitT; t.shflag = c->shflag; t.scene_abs = sabs;
             t.ovf = c->d_ovf; t.ovf_depth = c->ovf_depth; t.counters = c->d_testctr; t.status = c->d_status;
         };
         for (int b = 0; b < p->bounces; b++) {
@@ -839,6 +854,33 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
         FrameBuffers fb{};
         fb.accum = c->accum; fb.tile_ids = c->d_tiles;
         launch_convert(fp, fb, spp > 1 ? c->sum : nullptr, (uint8_t*)dev_bgr, c->stream);
+        mark(c, EV_CONVERT);
+    }
+    };
+    if (!p->use_graph) {
+        mark(c, EV_START);
+        enqueue();
+    } else {
+        crt_ctx::GraphKey key{};
+        key.cam = *cam; key.p = *p; key.lights = lights;
+        const void* ptrs[12] = {c->d_blob, c->rayO[0], c->rayO[1], c->hitSlot, c->rc, c->contrib, c->shO, c->accum, c->d_ctr, dev_bgr,
+                                c->d_tiles, c->cap_ids};
+        memcpy(key.ptrs, ptrs, sizeof ptrs);
+        key.nnodes = c->hdr.nnodes; key.nprims = c->hdr.nprims; key.mode = c->hdr.mode;
+        key.counting = c->counting; key.capture = c->capture; key.grid = c->grid_blocks; key.scene_abs = sabs;
+        if (!c->graph_exec || memcmp(&key, &c->graph_key, sizeof key) != 0) {
+            if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+            if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
+            HIPCHECK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+            c->in_capture = true;
+            enqueue();
+            c->in_capture = false;
+            HIPCHECK(c, hipStreamEndCapture(c->stream, &c->graph));
+            HIPCHECK(c, hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
+            memcpy(&c->graph_key, &key, sizeof key);
+        }
+        mark(c, EV_START);
+        HIPCHECK(c, hipGraphLaunch(c->graph_exec, c->stream));
         mark(c, EV_CONVERT);
     }
     HIPCHECK(c, hipGetLastError());

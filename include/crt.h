@@ -76,7 +76,10 @@ typedef struct crt_params {
     int32_t sort_rays;       /* 0/1: visit reflection and shadow rays in Morton order of their origin's cell (32^3 grid over
                               * the scene box; wide BVH only).  Changes the visiting order only, never the image. */
     int32_t area_samples;    /* shadow rays per area light and shading point, 1..64; 0 = 30 (lightSamples, Ray.cu:566) */
-    int32_t reserved[6];
+    int32_t use_graph;       /* 0/1: capture the frame's launch sequence in a HIP graph and replay it while camera, parameters,
+                              * lights and buffers stay the same (scene contents may move: animation + refit).  For small,
+                              * launch-bound frames; per-kernel times in crt_stats are then 0, ms_total stays */
+    int32_t reserved[5];
 } crt_params;
 
 typedef struct crt_stats {

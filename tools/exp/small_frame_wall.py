@@ -23,3 +23,9 @@ for w, h, b in ((720, 360, 1), (720, 360, 2), (1920, 1080, 4)):
     for _ in range(n):
         img = ctx.render(cam, tgt, p)
     print(f"    with the copy to the host: wall {(time.perf_counter() - t0) / n * 1e3:.3f} ms/frame")
+    g = crt.default_params(width=w, height=h, bounces=b, use_graph=1)
+    for _ in range(20): ctx.render_device(cam, tgt, g)
+    t0 = time.perf_counter(); dev = 0.0
+    for _ in range(n):
+        ctx.render_device(cam, tgt, g); dev += ctx.stats()["ms_total"]
+    print(f"    replayed as a HIP graph: wall {(time.perf_counter() - t0) / n * 1e3:.3f} ms/frame, device {dev / n:.3f} ms")
