@@ -190,6 +190,7 @@ void startRayTracing(float width, float height, unsigned char*& pixelcolorBuffer
     if (!ok(crt_lights_set(g_ctx, ls.data(), (int)ls.size()), "startRayTracing/crt_lights_set")) return;
     crt_params p; crt_params_default(&p);
     p.width = (int)width; p.height = (int)height; p.bounces = numBounces;
+    p.use_graph = 1;        /* the application's camera and frame size rarely change (main.cu:459,508): replay the launches */
     crt_camera cam; put(cam.position, cameraPosition); put(cam.target, cameraDirection);
     ok(crt_render(g_ctx, &cam, &p, pixelcolorBuffer), "startRayTracing/crt_render");
 }

@@ -66,7 +66,7 @@ int main(int argc, char** argv) {
     for (int f = 0; f < frames; f++) {
         auto t0 = std::chrono::steady_clock::now();
         if (f > 0) {
-            if (f % rebuild_every == 0) { freeTree(root); leafs.clear(); root = new Node(); newBuild(root, leafs, scene); }
+            if (rebuild_every > 0 && f % rebuild_every == 0) { freeTree(root); leafs.clear(); root = new Node(); newBuild(root, leafs, scene); }
             else refitTree(leafs);
         }
         startRayTracing(width, height, buffer1, cameraPosition, cameraDirection, scene, lights, root);
