@@ -771,6 +771,7 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
      * captured with, so graph mode rounds it up to a power of two (a larger pad is as conservative) and re-captures
      * only when an animated scene outgrows it */
     float sabs = c->scene_abs;
+    const int gb = c->grid_blocks;
     if (p->use_graph) { int e = 0; (void)frexpf(sabs > 0.f ? sabs : 1.f, &e); sabs = ldexpf(1.0f, e); }
     auto enqueue = [&]() {
     for (int s = 0; s < spp; s++) {
@@ -804,7 +805,7 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
                 TraceArgs ta{};
                 common(ta, 2 * b);
                 ta.rayO = fb.rayO; ta.rayD = fb.rayD; ta.count = ctr + b;
-                launch_trace(ta, TRACE_NEAREST, c->counting, wide, c->grid_blocks, c->stream);
+                launch_trace(ta, TRACE_NEAREST, c->counting, wide, gb, c->stream);
                 mark(c, EV_TRACE_N);
             }
             launch_shade(fp, fb, sv, lights, ctr + b, ctr + b + 1, ctr + 16 + b, c->stream);
@@ -833,7 +834,7 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
                     }
                 }
                 if (has_sh || has_nx) {
-                    launch_trace(tm, TRACE_NEAREST, c->counting, true, c->grid_blocks, c->stream);
+                    launch_trace(tm, TRACE_NEAREST, c->counting, true, gb, c->stream);
                     mark(c, has_sh && has_nx ? EV_TRACE_M : (has_sh ? EV_TRACE_S : EV_TRACE_N));
                 }
             } else if (c->lights.n > 0) {
@@ -841,7 +842,7 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
                 common(ts, 2 * b + 1);
                 ts.rayO = c->shO; ts.rayD = c->shD; ts.count = ctr + 16 + b;
                 ts.hitSlot = nullptr; ts.hitT = nullptr; ts.counters = c->d_testctr + 16;
-                launch_trace(ts, TRACE_SHADOW, c->counting, false, c->grid_blocks, c->stream);
+                launch_trace(ts, TRACE_SHADOW, c->counting, false, gb, c->stream);
                 mark(c, EV_TRACE_S);
             }
             launch_resolve(fb, lights, ctr + b, c->stream);

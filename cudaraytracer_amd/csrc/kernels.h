@@ -32,6 +32,7 @@ namespace crt {
 #endif
 constexpr int kFetchChunk = CRT_FETCH_CHUNK;       /* rays a wave takes from the queue per atomic */
 constexpr int kFetchStride = 64;       /* uint32 words between the 8 per-region fetch counters (256 B apart) */
+constexpr int kFetchDoneWord = 32;     /* word of the same zeroed block (its own 128-byte line): bit r = region r is used up */
 constexpr int kTraceBlock = 256;       /* 4 waves of 64 */
 constexpr int kStackDepth = CRT_STACK_DEPTH;        /* per-lane entries in LDS: stack[depth][lane], conflict-free per wave */
 #ifndef CRT_REFILL8_MIN_IDLE

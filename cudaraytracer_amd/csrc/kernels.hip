@@ -172,7 +172,20 @@ __global__ CRT_TRACE_BOUNDS void k_trace(TraceArgs A) {
                             cnext = rbeg + base;
                             cend = cnext + (uint32_t)kFetchChunk < rend ? cnext + (uint32_t)kFetchChunk : rend;
                             got = true;
-                        } else region_k++;
+                        } else {
+                            /* used up.  When a launch ends every wave finds every region used up, and eight failing atomics
+                             * per wave on eight addresses serialise (a tenth of a millisecond per launch): the first wave to
+                             * fail on a region says so in a shared mask, and a wave that has just failed skips what the mask
+                             * already rules out */
+                            region_k++;
+                            uint32_t done = 0;
+                            if (lane == 0) {
+                                done = __hip_atomic_load(A.next + kFetchDoneWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (rbeg < rend && !((done >> r) & 1u)) atomicOr(A.next + kFetchDoneWord, 1u << r);
+                            }
+                            done = __builtin_amdgcn_readfirstlane(done);
+                            while (region_k < 8 && ((done >> ((xcd + region_k) & 7u)) & 1u)) region_k++;
+                        }
                     }
                     if (!got) exhausted = true;
                 }
@@ -487,7 +500,20 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                             cnext = rbeg + base;
                             cend = cnext + (uint32_t)kFetchChunk < rend ? cnext + (uint32_t)kFetchChunk : rend;
                             got = true;
-                        } else region_k++;
+                        } else {
+                            /* used up.  When a launch ends every wave finds every region used up, and eight failing atomics
+                             * per wave on eight addresses serialise (a tenth of a millisecond per launch): the first wave to
+                             * fail on a region says so in a shared mask, and a wave that has just failed skips what the mask
+                             * already rules out */
+                            region_k++;
+                            uint32_t done = 0;
+                            if (lane == 0) {
+                                done = __hip_atomic_load(A.next + kFetchDoneWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (rbeg < rend && !((done >> r) & 1u)) atomicOr(A.next + kFetchDoneWord, 1u << r);
+                            }
+                            done = __builtin_amdgcn_readfirstlane(done);
+                            while (region_k < 8 && ((done >> ((xcd + region_k) & 7u)) & 1u)) region_k++;
+                        }
                     }
                     if (!got) exhausted = true;
                 }
