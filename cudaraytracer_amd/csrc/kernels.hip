@@ -1239,7 +1239,10 @@ __global__ CRT_SHADE_BOUNDS void k_shade(FrameParams P, FrameBuffers B, SceneVie
 
 void launch_shade(const FrameParams& fp, const FrameBuffers& fb, const SceneView& sv, const LightsParam& lights,
                   const uint32_t* count, uint32_t* next_count, uint32_t* shadow_count, hipStream_t s) {
-    hipLaunchKernelGGL(k_shade, dim3(4096), dim3(256), 0, s, fp, fb, sv, lights, count, next_count, shadow_count);
+    /* grid-stride over the queue; no more blocks than the queue can have entries */
+    uint32_t blocks = (fb.cap + 255u) / 256u;
+    blocks = blocks < 1u ? 1u : (blocks > 4096u ? 4096u : blocks);
+    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, s, fp, fb, sv, lights, count, next_count, shadow_count);
 }
 
 /* isectPoints[i].color += reflectionCoef * color (Ray.cu:660), colour summed over lights in order
@@ -1281,7 +1284,9 @@ __global__ __launch_bounds__(256) void k_resolve(FrameBuffers B, LightsParam LP,
 }
 
 void launch_resolve(const FrameBuffers& fb, const LightsParam& lights, const uint32_t* count, hipStream_t s) {
-    hipLaunchKernelGGL(k_resolve, dim3(4096), dim3(256), 0, s, fb, lights, count);
+    uint32_t blocks = (fb.cap + 255u) / 256u;
+    blocks = blocks < 1u ? 1u : (blocks > 4096u ? 4096u : blocks);
+    hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, s, fb, lights, count);
 }
 
 /* ------------------------------------------------------------------------------------------
