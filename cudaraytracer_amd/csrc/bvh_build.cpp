@@ -399,7 +399,7 @@ int build_wide(const crt_prim* prims, int n, const RefTree* ref, HostBVH& out) {
                 for (int s = 0; s < 8; s++) {
                     if (slot_used[s]) continue;
                     const float c = ((s & 4) ? v[0] : -v[0]) + ((s & 2) ? v[1] : -v[1]) + ((s & 1) ? v[2] : -v[2]);
-                    if (c > bc) { bc = c; bi = i; bs = s; }
+                    if (c > bc || bi < 0) { bc = c; bi = i; bs = s; }      /* bi < 0: a NaN offset still gets a slot (as lbvh.hip) */
                 }
             }
             kid_done[bi] = true; slot_used[bs] = true; slot_of_kid[bi] = bs;

@@ -69,7 +69,7 @@ struct crt_ctx {
      * contents changes */
     struct GraphKey {
         crt_camera cam; crt_params p; LightsParam lights;
-        const void* ptrs[12]; uint32_t nnodes, nprims, mode; int counting, capture, grid; float scene_abs;
+        const void* ptrs[20]; uint32_t nnodes, nprims, nmats, depth, mode; int counting, capture, grid, ovf_depth; float scene_abs;
     };
     GraphKey graph_key{}; hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; bool in_capture = false;
     unsigned char* h_stage = nullptr; size_t stage_cap = 0;     /* pinned staging for crt_render's copy to the caller's buffer */
@@ -311,6 +311,18 @@ void export_nodes(const std::vector<N>& nodes, float* child_boxes, uint32_t* chi
     }
 }
 
+/* the builders and the refit assume finite boxes: a NaN or infinite coordinate is an argument error, not a scene */
+bool finite_geometry(const crt_prim* prims, int n) {
+    for (int i = 0; i < n; i++) {
+        const crt_prim& p = prims[i];
+        float acc = 0.f;          /* x * 0 is 0 for every finite x and NaN otherwise */
+        if (p.type == 0) acc = p.position[0] * 0.f + p.position[1] * 0.f + p.position[2] * 0.f + p.radius * 0.f;
+        else for (int k = 0; k < 3; k++) acc += p.v1[k] * 0.f + p.v2[k] * 0.f + p.v3[k] * 0.f;
+        if (!(acc == 0.f)) return false;
+    }
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -373,6 +385,7 @@ int crt_scene_set(crt_ctx* c, const crt_prim* prims, int n) {
     if (n > CRT_MAX_PRIMS) return fail(c, CRT_ERR_ARG, "crt_scene_set: too many primitives");
     for (int i = 0; i < n; i++)
         if (prims[i].type != 0 && prims[i].type != 1) return fail(c, CRT_ERR_ARG, "crt_scene_set: type must be 0 (sphere) or 1 (triangle)");
+    if (!finite_geometry(prims, n)) return fail(c, CRT_ERR_ARG, "crt_scene_set: non-finite coordinate");
     HIPCHECK(c, hipSetDevice(c->device));
     c->prims.assign(prims, prims + n);
     dedupe_materials(c);
@@ -386,6 +399,7 @@ int crt_scene_update(crt_ctx* c, const crt_prim* prims, int n) {
     if ((size_t)n != c->prims.size()) return fail(c, CRT_ERR_ARG, "crt_scene_update: count differs from crt_scene_set");
     for (int i = 0; i < n; i++)
         if (prims[i].type != c->prims[i].type) return fail(c, CRT_ERR_ARG, "crt_scene_update: primitive type changed");
+    if (!finite_geometry(prims, n)) return fail(c, CRT_ERR_ARG, "crt_scene_update: non-finite coordinate");
     HIPCHECK(c, hipSetDevice(c->device));
     c->host_stale = false;
     /* materials keep their ids: only geometry (and normals) move, main.cu:545-573 */
@@ -864,11 +878,14 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
     } else {
         crt_ctx::GraphKey key{};
         key.cam = *cam; key.p = *p; key.lights = lights;
-        const void* ptrs[12] = {c->d_blob, c->rayO[0], c->rayO[1], c->hitSlot, c->rc, c->contrib, c->shO, c->accum, c->d_ctr, dev_bgr,
-                                c->d_tiles, c->cap_ids};
+        /* everything a captured launch bakes in: every buffer (size_overflow() may move d_ovf and change ovf_depth on any
+         * rebuild or import that leaves the blob's address and counts as they were), every header field the offsets derive from */
+        const void* ptrs[20] = {c->d_blob, c->rayO[0], c->rayO[1], c->hitSlot, c->rc, c->contrib, c->shO, c->accum, c->d_ctr, dev_bgr,
+                                c->d_tiles, c->cap_ids, c->d_ovf, c->d_sortkeys, c->d_sortperm, c->d_sortkeys2, c->d_sortperm2, c->d_sorthist,
+                                c->d_area_table, c->sum};
         memcpy(key.ptrs, ptrs, sizeof ptrs);
-        key.nnodes = c->hdr.nnodes; key.nprims = c->hdr.nprims; key.mode = c->hdr.mode;
-        key.counting = c->counting; key.capture = c->capture; key.grid = c->grid_blocks; key.scene_abs = sabs;
+        key.nnodes = c->hdr.nnodes; key.nprims = c->hdr.nprims; key.nmats = c->hdr.nmats; key.depth = c->hdr.depth; key.mode = c->hdr.mode;
+        key.counting = c->counting; key.capture = c->capture; key.grid = c->grid_blocks; key.ovf_depth = c->ovf_depth; key.scene_abs = sabs;
         if (!c->graph_exec || memcmp(&key, &c->graph_key, sizeof key) != 0) {
             if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
             if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }

@@ -26,6 +26,9 @@ namespace crt {
 
 #define CRT_DEV __device__ __forceinline__
 
+static_assert(kFetchChunk >= 1 && (kFetchChunk & (kFetchChunk - 1)) == 0, "CRT_FETCH_CHUNK must be a power of two");
+constexpr uint32_t kRegionAlign = kFetchChunk > 64 ? (uint32_t)kFetchChunk : 64u;      /* region size granule: a multiple of the chunk and of a wave */
+
 /* ------------------------------------------------------------------------------------------
  * primitive tests
  * ------------------------------------------------------------------------------------------ */
@@ -110,7 +113,7 @@ __global__ CRT_TRACE_BOUNDS void k_trace(TraceArgs A) {
     uint32_t cnext = 0, cend = 0;    /* wave-uniform: this wave's private chunk [cnext, cend) */
     /* HW_REG_XCC_ID (id 20), bits [3:0]: which XCD this wave runs on.  Used for L2 affinity only. */
     const uint32_t xcd = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
-    const uint32_t per_region = (((total + 7u) >> 3) + 63u) & ~63u;
+    const uint32_t per_region = (((total + 7u) >> 3) + kRegionAlign - 1u) & ~(kRegionAlign - 1u);     /* whole chunks: a chunk never straddles two regions or two queues */
     uint32_t region_k = 0;           /* wave-uniform: regions (starting at this XCD's) already found empty */
     vec3 o, d;
     float ix = 0, iy = 0, iz = 0, ax = 0, ay = 0, az = 0, bx = 0, by = 0, bz = 0;
@@ -458,7 +461,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
     bool exhausted = false;
     uint32_t cnext = 0, cend = 0;
     const uint32_t xcd = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
-    const uint32_t per_region = (((total + 7u) >> 3) + 63u) & ~63u;
+    const uint32_t per_region = (((total + 7u) >> 3) + kRegionAlign - 1u) & ~(kRegionAlign - 1u);     /* whole chunks: a chunk never straddles two regions or two queues */
     uint32_t region_k = 0;
     vec3 o, d;
     float ix = 0, iy = 0, iz = 0, anx = 0, afx = 0, any_ = 0, afy = 0, anz = 0, afz = 0;
