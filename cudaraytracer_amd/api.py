@@ -67,7 +67,7 @@ ABI_SYMBOLS = [
     "crt_scene_set", "crt_scene_update", "crt_lights_set", "crt_animate_device", "crt_scene_get",
     "crt_bvh_build", "crt_bvh_refit", "crt_bvh_free", "crt_bvh_reference_order", "crt_bvh_dump",
     "crt_render", "crt_render_device", "crt_set_capture", "crt_get_capture", "crt_get_color",
-    "crt_trace", "crt_trace_shadow",
+    "crt_trace", "crt_trace_shadow", "crt_trace_noalloc",
     "crt_blob_size", "crt_blob_device_ptr", "crt_blob_import_device",
     "crt_tile_owner", "crt_tiles_owned", "crt_tiles_pack", "crt_tiles_unpack",
     "crt_get_stats", "crt_sync",
@@ -96,6 +96,7 @@ for _name, _args in {
     "crt_render_device": [_vp, C.POINTER(Camera), C.POINTER(Params), _vp],
     "crt_get_capture": [_vp, _i, _vp, _vp, _i], "crt_get_color": [_vp, _vp, _i],
     "crt_trace": [_vp, _vp, _i, _vp, _vp], "crt_trace_shadow": [_vp, _vp, _i, _vp],
+    "crt_trace_noalloc": [_vp, _vp, _i, _vp, _vp],
     "crt_blob_size": [_vp, C.POINTER(C.c_size_t)], "crt_blob_device_ptr": [_vp, C.POINTER(_vp)],
     "crt_blob_import_device": [_vp, _vp, C.c_size_t],
     "crt_tile_owner": [_i, _i], "crt_tiles_owned": [C.POINTER(Params), _vp, _vp, _vp, _i],
@@ -363,6 +364,10 @@ class Context:
         ts = np.zeros(n, np.float32)
         self._ck(lib.crt_trace(self.h, _ptr(rays6), n, _ptr(ids), _ptr(ts)))
         return ids, ts
+
+    def trace_noalloc(self, dev_rays6, n, dev_ids, dev_ts):
+        """crt_trace_noalloc: device pointers in and out, no allocation inside the call."""
+        self._ck(lib.crt_trace_noalloc(self.h, dev_rays6, n, dev_ids, dev_ts))
 
     def trace_shadow(self, rays6):
         rays6 = np.ascontiguousarray(rays6, np.float32).reshape(-1, 6)

@@ -11,6 +11,7 @@
  */
 #include "../../include/crt.h"
 #include "kernels.h"
+#include "internal.h"
 #include "bvh_build.h"
 #include "vec.h"
 #include <hip/hip_runtime.h>
@@ -85,6 +86,8 @@ struct crt_ctx {
     Node8* d_lbvh_nodes = nullptr; size_t lbvh_nodes_cap = 0;    /* its output before the blob is laid out */
     uint32_t* d_lbvh_s2s = nullptr; size_t lbvh_s2s_cap = 0;
     uint32_t* d_status = nullptr;
+    uint32_t* h_status = nullptr;      /* pinned: crt_trace_noalloc reads the status word without a staging copy */
+    void* noalloc_scratch = nullptr;   /* this device's copy of noalloc.hip's scratch array (address looked up once per device) */
     unsigned long long* d_testctr = nullptr;
     uint32_t* d_ovf = nullptr; size_t ovf_cap = 0; int ovf_depth = 0;
     int grid_blocks = 1024;
@@ -311,6 +314,9 @@ void export_nodes(const std::vector<N>& nodes, float* child_boxes, uint32_t* chi
     }
 }
 
+}  // namespace
+
+namespace {
 /* the builders and the refit assume finite boxes: a NaN or infinite coordinate is an argument error, not a scene */
 bool finite_geometry(const crt_prim* prims, int n) {
     for (int i = 0; i < n; i++) {
@@ -322,8 +328,20 @@ bool finite_geometry(const crt_prim* prims, int n) {
     }
     return true;
 }
-
 }  // namespace
+
+namespace crt {
+int ctx_fail(crt_ctx* c, int code, const char* msg) { return fail(c, code, msg); }
+int ctx_trace_view(crt_ctx* c, TraceView* v) {
+    if (!c || !v) return CRT_ERR_ARG;
+    v->built = c->built;
+    v->sv = c->built ? view_of(c) : SceneView{};
+    v->stream = c->stream; v->device = c->device; v->wide = c->hdr.mode == CRT_BVH_WIDE;
+    v->scene_abs = c->scene_abs; v->ovf = c->d_ovf; v->ovf_depth = c->ovf_depth;
+    v->counters = c->d_testctr; v->status = c->d_status; v->h_status = c->h_status; v->grid_blocks = c->grid_blocks;
+    return CRT_OK;
+}
+}  // namespace crt
 
 extern "C" {
 
@@ -336,6 +354,7 @@ crt_ctx* crt_create(int device, int* err) {
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void**)&c->d_status, 4) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_status, 64, hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void**)&c->d_testctr, 32 * sizeof(unsigned long long)) != hipSuccess) {
         if (err) *err = CRT_ERR_HIP;
         delete c;
@@ -344,6 +363,12 @@ crt_ctx* crt_create(int device, int* err) {
     hipMemset(c->d_status, 0, 4);
     hipMemset(c->d_testctr, 0, 32 * sizeof(unsigned long long));
     c->grid_blocks = trace_grid_blocks(device);
+    {   /* crt_trace_noalloc's scratch array: its address on THIS device, looked up while this device is current */
+        hipError_t se = hipSuccess;
+        c->noalloc_scratch = noalloc_scratch_for_device(device, &se);
+        if (!c->noalloc_scratch) { if (err) *err = CRT_ERR_HIP; crt_destroy(c); return nullptr; }
+    }
+    *c->h_status = 0;
     if (err) *err = CRT_OK;
     return c;
 }
@@ -359,6 +384,7 @@ void crt_destroy(crt_ctx* c) {
                     c->d_lbvh, c->d_lbvh_nodes, c->d_lbvh_s2s, c->d_area_table};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_stage) hipHostFree(c->h_stage);
+    if (c->h_status) hipHostFree(c->h_status);
     if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
     if (c->graph) hipGraphDestroy(c->graph);
     for (uint32_t* q : c->tl_ids) if (q) hipFree(q);

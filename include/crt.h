@@ -170,6 +170,16 @@ int crt_trace(crt_ctx*, const float* org_dir /* 6n host floats */, int n, int32_
 /* shadow predicate of Ray.cu:650-656 for directional lights: out[i]=1 iff a hit exists and the
  * nearest hit has t > 1e-9 */
 int crt_trace_shadow(crt_ctx*, const float* org_dir, int n, uint8_t* shadowed_out);
+/* crt_trace for callers that cannot allocate.  No counterpart in the reference (like crt_trace itself); it exists for
+ * code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc: crt_trace allocates and frees
+ * its working buffers on every call, this entry point calls no hipMalloc / hipFree / event or other allocating
+ * routine.  Same kernels, same results; rays and results are DEVICE pointers (6n floats in, n ids and n t out).  The
+ * working buffers (packed ray queue, hit slots, fetch counters) live in one fixed device array per GPU of
+ * 36 MiB + 4 KiB, held until the process ends, which bounds n: CRT_ERR_ARG beyond CRT_NOALLOC_MAX_RAYS.  All calls on
+ * one GPU share that array: calls that overlap on one GPU (two contexts, two threads) race -- serialise them.
+ * Returns with the results complete (the context's stream is synchronised). */
+#define CRT_NOALLOC_MAX_RAYS (1 << 20)
+int crt_trace_noalloc(crt_ctx*, const float* dev_org_dir, int n, int32_t* dev_prim_out, float* dev_t_out);
 
 /* ---- multi-GPU plumbing: the packed scene + BVH is one device blob that the host layer
  *      broadcasts (RCCL) and imports on the other ranks ---- */
