@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric on its own workload: Mrays/s (primary + shadow + reflection
 traversals actually issued) and frame ms on the synthetic 1M-triangle soup at 3840x2160, bounces=3
-(configs[3]); on N GPUs the frame grows with N at a fixed pixel count per GPU and its tiles are sharded over the
-ranks (weak scaling, configs[4]'s mechanism; --strong shards the same 4K frame instead).
+(configs[3]).  On N GPUs the SAME frame is sharded by 32x32 tiles over the ranks (strong scaling: BASELINE's metric is
+"1M-tri 4K scene, 1/2/4/8 GPU"); --config 4 selects configs[4] (7680x4320 x 16 spp), --weak grows the frame with N at a
+fixed pixel count per GPU instead.
 
 A "step" is one frame of the hot path: gen_primary -> [trace -> shade -> shadow trace -> resolve] x
 bounces -> convert, with the scene + BVH already resident in HBM and the frame left in HBM
@@ -26,7 +27,10 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-VALU_ISSUE_PEAK_G = 256 * 4 * 2.4 / 4    # 256 CUs x 4 SIMDs, one 64-wide VALU instruction per SIMD per 4 clocks, 2.4 GHz
+N_SIMD = 256 * 4          # 256 CUs x 4 SIMDs
+UBENCH_VALU = os.path.join(ROOT, "profiles", "r02_ubench_valu_issue.jsonl")    # tools/ubench/valu_issue.hip on MI355X
+UBENCH_L1 = os.path.join(ROOT, "profiles", "r02_ubench_l1_gather.jsonl")       # tools/ubench/l1_gather.hip on MI355X
+ISA_MIX = os.path.join(ROOT, "cudaraytracer_amd", "isa_mix_k_trace8.json")     # tools/isa_mix.py, written by the build
 _T0 = time.perf_counter()
 
 
@@ -36,10 +40,56 @@ def log(msg):
         print(f"[bench {time.perf_counter() - _T0:7.2f}s] {msg}", file=sys.stderr, flush=True)
 
 
-def algorithmic_bytes(nrays, nbox, ntri, nsph):
-    """32 B per AABB test (24 B bounds + 8 B link), 36 B per triangle test (9 floats),
-    16 B per sphere test, 48 B per ray (32 B ray record + 16 B hit record)."""
+def survey_bytes(nrays, nbox, ntri, nsph):
+    """SURVEY.md 8(d)'s formula, kept as a labelled secondary: 32 B per AABB test (24 B bounds + 8 B link), 36 B per
+    triangle test (9 floats), 16 B per sphere test, 48 B per ray (32 B ray record + 16 B hit record).  It prices a
+    layout this build does not have (a QNode8 holds a child in 10 B), so it is NOT the roofline's numerator."""
     return 32 * nbox + 36 * ntri + 16 * nsph + 48 * nrays
+
+
+def layout_bytes(nrays, nvisits, nprim_tests):
+    """Bytes the traversal actually requests with the layout it reads (layout.h): 80 B per node visit (QNode8), 48 B per
+    primitive test (Geom), 48 B per ray (two float4 in, hit slot + t or a shadow flag out)."""
+    return 80 * nvisits + 48 * nprim_tests + 48 * nrays
+
+
+def valu_issue_model(cst):
+    """VALU wave-instructions and VALU issue cycles of the frame's k_trace8 launches: the wave-level iteration counts of
+    the counting frame (crt_stats.sched_*) times the per-region instruction counts of the compiled kernel, every opcode
+    priced with its measured issue cost (tools/isa_mix.py <- tools/ubench/valu_issue.hip).  Sub-branches of a region
+    that no lane takes are skipped by the hardware but counted here, so both figures are upper estimates; the
+    instruction count is checked against SQ_INSTS_VALU of the committed PMC pass (roofline.model_check)."""
+    mix = json.load(open(ISA_MIX))
+    R = mix["regions"]
+
+    def reg(name):
+        r = R.get(name, {"valu": 0, "valu_issue_cycles": 0.0})
+        return np.array([r["valu"], r["valu_issue_cycles"]], np.float64)
+    it, node, prim = cst["sched_iterations"], cst["sched_node_iterations"], cst["sched_prim_iterations"]
+    sph = prim if cst["sph_tests"] + cst["sph_tests_shadow"] > 0 else 0
+    times = {"prologue": cst["trace_waves"], "refill1": cst["sched_refill_iterations"], "between_refill1": it, "vote": it, "between_vote": it,
+             "node": node, "pop": cst["sched_pop_iterations"], "between_pop": node, "between_node": node,
+             "prim": prim, "decode": cst["sched_decode_iterations"], "between_decode": prim, "sphere": sph, "between_sphere": prim,
+             "hit": cst["sched_hit_iterations"], "between_hit": prim, "between_prim": prim,
+             "finish": cst["sched_finish_iterations"], "between_finish": it, "refill2": cst["sched_setup_iterations"], "between_refill2": it}
+    tot = np.zeros(2)
+    mix["breakdown"] = {}
+    for name in R:
+        if name not in times:
+            raise KeyError(f"isa_mix region {name} has no iteration count in bench.py")
+        tot = tot + times[name] * reg(name)
+        if times[name] and R[name]["valu"]:
+            mix["breakdown"][name] = {"executions": int(times[name]), "valu_per_execution": R[name]["valu"],
+                                      "issue_cycles_per_execution": R[name]["valu_issue_cycles"]}
+    return float(tot[0]), float(tot[1]), mix
+
+
+def ubench_line(path, key, value, k):
+    for line in open(path):
+        r = json.loads(line)
+        if r.get(key, "").startswith(value) and r.get("waves_per_simd") == k:
+            return r
+    return None
 
 
 def cpu_baseline(prims, lights, cam, tgt, width, height, bounces, max_threads):
@@ -70,7 +120,19 @@ def cpu_baseline(prims, lights, cam, tgt, width, height, bounces, max_threads):
     dt = time.perf_counter() - t0
     st = sc.stats(reset=True)
     sc.close()
+    # the reference's own case beside it (configs[0]: teapot + sphere, 720x360, bounces = 1, the whole frame)
+    import cudaraytracer_amd as crt
+    tp = orc.Scene(crt.scene_teapot(with_sphere=True))
+    tp.build()
+    tp.stats(reset=True)
+    t0 = time.perf_counter()
+    tp.render(lights, cam, tgt, 720, 360, 1, nthreads=cores)
+    dt0 = time.perf_counter() - t0
+    st0 = tp.stats(reset=True)
+    tp.close()
     return {
+        "reference_case": {"workload": "configs[0]: teapot3.obj + sphere, 720x360, bounces=1, whole frame", "value": round(st0["traversals"] / dt0 / 1e6, 3),
+                           "unit": "Mrays/s", "frame_ms": round(dt0 * 1e3, 2), "traversals": st0["traversals"], "cores": cores},
         "value": round(st["traversals"] / dt / 1e6, 6), "unit": "Mrays/s", "cores": cores, "kind": "port",
         "sample": f"centred {rect[2] - rect[0]}x{rect[3] - rect[1]} sub-rectangle of the {width}x{height} frame, "
                   f"bounces={bounces}: {st['traversals']} traversals issued by the reference's logic "
@@ -85,18 +147,28 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=3, help="BASELINE.json configs index: 3 = 1M soup 3840x2160 bounces=3 (the metric's config), "
+                    "4 = the same soup at 7680x4320 x 16 spp")
     ap.add_argument("--tris", type=int, default=1000000)
-    ap.add_argument("--width", type=int, default=3840)
-    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--bounces", type=int, default=3)
-    ap.add_argument("--spp", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--bvh", type=int, default=0, help="0 wide SAH built on the host (default), 1 reference topology, 2 wide LBVH built on the device")
     ap.add_argument("--sort-rays", type=int, default=0, help="1: visit secondary rays in Morton order of their origin cell")
-    ap.add_argument("--strong", action="store_true", help="N > 1: shard the SAME --width x --height frame (strong scaling)")
+    ap.add_argument("--weak", action="store_true", help="N > 1: grow the frame with N at a fixed pixel count per GPU (weak scaling) "
+                    "instead of sharding the same frame")
+    ap.add_argument("--strong", action="store_true", help="(default since round 2; kept for old command lines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--out-bmp", default=None)
     a = ap.parse_args()
+    if a.config not in (3, 4):
+        sys.exit("bench.py --config: 3 or 4 (the other BASELINE configs are parity-test cases, tools/bench_configs.py times them)")
+    cw, ch, cspp = (3840, 2160, 1) if a.config == 3 else (7680, 4320, 16)
+    a.width = a.width or cw
+    a.height = a.height or ch
+    a.spp = a.spp or cspp
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -116,11 +188,10 @@ def main():
 
     cam, tgt = crt.default_camera()
     lights = crt.default_lights()
-    # N > 1: WEAK scaling -- the pixels per GPU stay those of the --width x --height frame and the frame grows with N
-    # (3840x2160, 7680x2160, 7680x4320, 15360x4320 for N = 1, 2, 4, 8; configs[4] is the N = 4 frame size); its tiles
-    # are sharded over the ranks and gathered to rank 0 every frame
+    # N > 1 shards the SAME frame (BASELINE's metric: "1M-tri 4K scene, 1/2/4/8 GPU").  --weak: the pixels per GPU stay
+    # those of the --width x --height frame and the frame grows with N (7680x2160, 7680x4320, 15360x4320 for N = 2, 4, 8)
     fw, fh = a.width, a.height
-    if world > 1 and not a.strong:
+    if world > 1 and a.weak:
         k = world.bit_length() - 1 if world & (world - 1) == 0 else None
         if k is None:
             fw = a.width * world
@@ -131,6 +202,7 @@ def main():
     prims = crt.scene_soup(a.tris, seed=1) if (rank == 0 or world == 1) else None
     log(f"scene generated: {a.tris} triangles")
 
+    phase = {"render": 0.0, "pack": 0.0, "gather": 0.0, "unpack": 0.0}
     if world > 1:
         # rehearsal on a one-GPU box: CRT_DIST_BACKEND=gloo CRT_FORCE_DEVICE=0 puts every rank on one device
         backend = os.environ.get("CRT_DIST_BACKEND", "nccl")
@@ -147,7 +219,7 @@ def main():
         ctx = sr.ctx
 
         def step():
-            sr.render(cam, tgt, params)
+            sr.render(cam, tgt, params, phase)
 
         def fence():
             torch.cuda.synchronize()
@@ -165,8 +237,8 @@ def main():
         def fence():
             ctx.sync()
 
-    # one untimed frame with the counting kernels: AABB / triangle / sphere test counts of exactly
-    # the traversal the timed kernels perform (same packed BVH, same order) -> algorithmic bytes
+    # one untimed frame with the counting kernels: test counts and wave-level iteration counts of exactly the traversal
+    # the timed kernels perform (same packed BVH, same order)
     log("scene + BVH resident; counting frame")
     ctx.set_counting(True)
     step()
@@ -177,6 +249,8 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
+    for k in phase:
+        phase[k] = 0.0
     log("timed steps")
     t0 = time.perf_counter()
     acc = {"ms_trace": 0.0, "ms_trace_nearest": 0.0, "ms_trace_shadow": 0.0, "ms_trace_mixed": 0.0, "ms_total": 0.0, "ms_shade": 0.0,
@@ -190,8 +264,8 @@ def main():
     elapsed = time.perf_counter() - t0
     log(f"timed steps done: {elapsed / a.steps * 1e3:.3f} ms/step")
 
-    rays_local = st["rays_primary"] + st["rays_shadow"] + st["rays_reflect"]
     rays = np.array([st["rays_primary"], st["rays_shadow"], st["rays_reflect"]], np.float64)
+    per_rank = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -199,55 +273,129 @@ def main():
         r = torch.tensor(rays, dtype=torch.float64, device="cuda")
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
         rays = r.cpu().numpy()
+        # per-rank phase times (ms per frame): device render, tile pack, gather, unpack
+        mine = torch.tensor([acc["ms_total"] / a.steps, phase["render"] / a.steps * 1e3, phase["pack"] / a.steps * 1e3,
+                             phase["gather"] / a.steps * 1e3, phase["unpack"] / a.steps * 1e3], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [[round(float(x), 4) for x in v.cpu().tolist()] for v in allr]
     total_rays = float(rays.sum())
 
     if rank == 0:
         ms_step = elapsed / a.steps * 1e3
-        # roofline of the dominant kernel on rank 0's launches.  Wide BVH: k_trace8 serves the shadow rays of a bounce
-        # and the nearest-hit rays of the next in one launch, so the kernel's figure covers all its launches of a
-        # frame (bounces + 1) and all their rays; reference topology: k_trace<NEAREST>'s own launches.
+        wide = a.bvh != 1
+        # ---- roofline of the dominant kernel on rank 0's launches.  k_trace8 serves the shadow rays of a bounce and the
+        # nearest-hit rays of the next in one launch, so the kernel's figure covers all its launches of a frame
+        # (bounces + 1 per sample pass) and all their rays.
         n_near = cst["rays_primary"] + cst["rays_reflect"]
-        bytes_near = algorithmic_bytes(n_near, cst["box_tests"], cst["tri_tests"], cst["sph_tests"])
-        bytes_shadow = algorithmic_bytes(cst["rays_shadow"], cst["box_tests_shadow"], cst["tri_tests_shadow"],
-                                         cst["sph_tests_shadow"])
-        if a.bvh != 1:
+        n_launch_c = max(1, cst["launches_trace_nearest"] + cst["launches_trace_shadow"] + cst["launches_trace_mixed"])
+        if wide:
             launches = max(1, acc["launches_trace_nearest"] + acc["launches_trace_shadow"] + acc["launches_trace_mixed"])
             avg_ms = acc["ms_trace"] / launches
-            per_launch_bytes = (bytes_near + bytes_shadow) / max(1, cst["launches_trace_nearest"] + cst["launches_trace_shadow"]
-                                                                  + cst["launches_trace_mixed"])
         else:
             launches = max(1, acc["launches_trace_nearest"])
             avg_ms = acc["ms_trace_nearest"] / launches
-            per_launch_bytes = bytes_near / max(1, cst["launches_trace_nearest"])
-        achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM-side bytes per launch of the same kernel from the committed PMC passes (rocprofv3 cannot be
-        # nested inside this process): only quoted for the default workload those passes measured
-        traffic = None
-        valu_instr = None
+            n_launch_c = max(1, cst["launches_trace_nearest"])
+        avg_s = avg_ms * 1e-3
+        visits = cst["node_visits"] + cst["node_visits_shadow"]
+        prim_tests = cst["tri_tests"] + cst["sph_tests"] + cst["tri_tests_shadow"] + cst["sph_tests_shadow"]
+        nrays_k = n_near + cst["rays_shadow"]
+        lay_b = layout_bytes(nrays_k, visits, prim_tests) / n_launch_c
+        sur_b = (survey_bytes(n_near, cst["box_tests"], cst["tri_tests"], cst["sph_tests"]) +
+                 survey_bytes(cst["rays_shadow"], cst["box_tests_shadow"], cst["tri_tests_shadow"], cst["sph_tests_shadow"])) / n_launch_c
+        # HBM-side bytes and SQ_INSTS_VALU per launch of the same kernel from the committed PMC passes (rocprofv3 cannot be
+        # nested inside this process): quoted, with their source, only for the default workload those passes measured
+        traffic = pmc_valu = None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
-        default_workload = (a.tris, a.width, a.height, a.bounces, a.spp, a.bvh, world) == (1000000, 3840, 2160, 3, 1, 0, 1)
+        default_workload = (a.tris, fw, fh, a.bounces, a.spp, a.bvh, world) == (1000000, 3840, 2160, 3, 1, 0, 1)
+        tsrc = None
         if default_workload and os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 traffic = float(tj["hbm_bytes_per_launch"])
-                valu_instr = tj.get("valu_wave_instructions_per_launch")
+                pmc_valu = tj.get("valu_wave_instructions_per_launch")
+                tsrc = "profiles/latest_traffic.json <- " + str(tj.get("source", ""))
             except Exception:
                 traffic = None
+        roof = {"kernel": "k_trace8" if wide else "k_trace<NEAREST>", "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches}
+        if wide and os.path.exists(ISA_MIX) and os.path.exists(UBENCH_VALU) and cst["sched_iterations"] > 0 and avg_s > 0:
+            n_instr, n_cycles, mix = valu_issue_model(cst)
+            n_instr /= n_launch_c
+            n_cycles /= n_launch_c
+            cpi = n_cycles / max(1.0, n_instr)           # issue cycles per instruction of this kernel's mix
+            # the model counts every instruction of a region, also sub-branches no lane takes (the hardware skips those): where the
+            # committed PMC pass of this binary and workload gives SQ_INSTS_VALU, the count is taken from it and the model gives the mix
+            cal = pmc_valu if pmc_valu else n_instr
+            ub = ubench_line(UBENCH_VALU, "class", "k_trace8 node step", 5)
+            clock = ub["clock_ghz"]
+            peak = N_SIMD * clock                       # G issue cycles per second the chip's SIMDs provide at the sustained clock
+            achieved = cal * cpi / avg_s / 1e9
+            roof.update({
+                "bound": "valu_issue", "unit": "G VALU issue-cycles/s",
+                "achieved": round(achieved, 1), "peak": round(peak, 1), "frac": round(achieved / peak, 4),
+                "frac_at_2.4GHz_spec_clock": round(achieved / (N_SIMD * 2.4), 4),
+                "definition": "achieved = VALU wave-instructions of one launch x issue cycles per instruction of the kernel's mix / launch duration "
+                              "measured in this run (HIP events on the kernel's stream).  Mix: wave-level iteration counts of this run's counting frame x "
+                              "per-region instruction counts of the compiled kernel, each opcode at the LOWEST issue cost measured for it at any occupancy "
+                              "(full-rate %.2f, half-rate %.2f, v_rcp/v_sqrt %.2f cycles per wave64 instruction per SIMD), so the sum is a lower bound of the "
+                              "cycles the stream needs.  peak = %d SIMDs x %.3f GHz, the clock the chip holds under the node step's instruction stream at 5 waves/SIMD"
+                              % (mix["cycles_full_rate"], mix["cycles_half_rate"], mix["cycles_quarter_rate"], N_SIMD, clock),
+                "peak_source": "profiles/r02_ubench_valu_issue.jsonl (tools/ubench/valu_issue.hip on MI355X); mix: cudaraytracer_amd/isa_mix_k_trace8.json (tools/isa_mix.py)",
+                "valu_wave_instructions_per_launch": int(cal),
+                "valu_wave_instructions_source": (tsrc + " (SQ_INSTS_VALU)") if pmc_valu else "model (upper estimate: counts sub-branches no lane takes)",
+                "valu_wave_instructions_per_launch_model": int(n_instr),
+                "model_over_pmc": round(n_instr / pmc_valu, 4) if pmc_valu else None,
+                "valu_g_wave_instructions_per_s": round(cal / avg_s / 1e9, 1),
+                "node_step_stream_ceiling_g_wave_instructions_per_s": ub["g_wave_instructions_per_s"],
+                "avg_issue_cycles_per_instruction": round(cpi, 3),
+                "regions_per_frame": mix["breakdown"],
+            })
+        else:
+            roof.update({"bound": "hbm", "unit": "GB/s", "achieved": round(lay_b / avg_s / 1e9, 2) if avg_s > 0 else 0.0, "peak": HBM_PEAK_GBS,
+                         "frac": round(lay_b / avg_s / 1e9 / HBM_PEAK_GBS, 5) if avg_s > 0 else 0.0})
+        # secondary figures, labelled: the bytes this layout requests (served by L1/L2/Infinity Cache: the 24 MB of qnodes and
+        # 48 MB of geom fit the 256 MB Infinity Cache, so HBM is not this kernel's roof), SURVEY 8(d)'s formula, the vector L1
+        l1 = ubench_line(UBENCH_L1, "pattern", "lane80", 5) if os.path.exists(UBENCH_L1) else None
+        lane_req = (5 * (cst["sched_node_lanes"]) + 3 * cst["sched_prim_lanes"] + 2 * nrays_k) / n_launch_c
+        roof["hbm_nominal"] = {"bytes_per_launch_layout": int(lay_b), "achieved_gbs": round(lay_b / avg_s / 1e9, 1) if avg_s > 0 else 0.0,
+                               "peak_gbs": HBM_PEAK_GBS, "ratio": round(lay_b / avg_s / 1e9 / HBM_PEAK_GBS, 4) if avg_s > 0 else 0.0,
+                               "bytes": "80 B per node visit (QNode8) + 48 B per primitive test (Geom) + 48 B per ray",
+                               "note": "requested bytes, cache-served (scene working set 72 MB < 256 MB Infinity Cache): not a bound, may exceed 1",
+                               "bytes_per_launch_survey_8d_formula": int(sur_b)}
+        roof["traffic"] = traffic
+        roof["traffic_source"] = tsrc
+        if l1 and avg_s > 0 and lane_req > 0:
+            roof["vector_l1"] = {"lane_requests_per_launch": int(lane_req), "achieved_g_lane_requests_per_s": round(lane_req / avg_s / 1e9, 1),
+                                 "ceiling_all_l1_hits": l1["g_lane_requests_per_s"],
+                                 "frac_of_l1_hit_ceiling": round(lane_req / avg_s / 1e9 / l1["g_lane_requests_per_s"], 4),
+                                 "source": "profiles/r02_ubench_l1_gather.jsonl: lane-divergent 16-byte loads of 80-byte records, L1-resident table, 5 waves/SIMD"}
+        roof["per_ray"] = {"node_visits": round(cst["node_visits"] / max(1, n_near), 2), "box_tests": round(cst["box_tests"] / max(1, n_near), 2),
+                           "tri_tests": round(cst["tri_tests"] / max(1, n_near), 2)}
+        roof["per_shadow_ray"] = {"node_visits": round(cst["node_visits_shadow"] / max(1, cst["rays_shadow"]), 2),
+                                  "box_tests": round(cst["box_tests_shadow"] / max(1, cst["rays_shadow"]), 2),
+                                  "tri_tests": round(cst["tri_tests_shadow"] / max(1, cst["rays_shadow"]), 2)}
+        if cst["sched_iterations"] > 0:
+            roof["schedule"] = {"node_iterations": cst["sched_node_iterations"], "lanes_per_node_iteration": round(cst["sched_node_lanes"] / max(1, cst["sched_node_iterations"]), 1),
+                                "prim_iterations": cst["sched_prim_iterations"], "lanes_per_prim_iteration": round(cst["sched_prim_lanes"] / max(1, cst["sched_prim_iterations"]), 1),
+                                "visits_no_child_hit_frac": round(cst["visits_no_child_hit"] / max(1, visits), 3)}
+        scaling = "weak" if a.weak else "strong"      # N > 1 shards the same frame unless --weak
         out = {
-            "metric": "Mrays/sec (primary+shadow+reflect), 1M-tri 4K scene",
+            "metric": "Mrays/sec (primary+shadow+reflect), 1M-tri 4K scene" if a.config == 3 and not a.weak else
+                      f"Mrays/sec (primary+shadow+reflect), 1M-tri {fw}x{fh} x{a.spp}spp scene",
             "value": round(total_rays * a.steps / elapsed / 1e6, 3),
             "unit": "Mrays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_step, 4),
             "higher_is_better": True,
-            "scaling": "strong" if a.strong else "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"configs[3]: synthetic {a.tris}-triangle random soup (seed 1), {fw}x{fh} ({a.width * a.height} pixels per GPU), "
+                "workload": f"configs[{a.config}]: synthetic {a.tris}-triangle random soup (seed 1), {fw}x{fh}, "
                             f"bounces={a.bounces} (primary + {a.bounces - 1} reflections), 2 directional lights, "
-                            f"spp={a.spp}; frame tiles 32x32 sharded over {world} GPU(s)" + ("; sorted secondary rays" if a.sort_rays else ""),
+                            f"spp={a.spp}; frame tiles 32x32 sharded over {world} GPU(s)" + (" (weak scaling: the frame grows with N)" if a.weak and world > 1 else "")
+                            + ("; sorted secondary rays" if a.sort_rays else ""),
                 "bvh": {0: "wide8-sah-compressed", 1: "reference-topology", 2: "wide8-lbvh-device-built"}[a.bvh],
                 "rays_per_frame": {"primary": int(rays[0]), "shadow": int(rays[1]), "reflect": int(rays[2])},
                 "frame_ms_device_rank0": round(acc["ms_total"] / a.steps, 4),
@@ -260,28 +408,10 @@ def main():
                 "bvh_nodes": cst["nodes"], "bvh_depth": cst["depth"], "scene_bytes": cst["scene_bytes"],
                 "bvh_build_host_ms": round(cst["ms_build_host"], 1), "bvh_build_device_ms": round(cst["ms_build_device"], 2),
             },
-            "roofline": {
-                "kernel": "k_trace8" if a.bvh != 1 else "k_trace<NEAREST>", "bound": "hbm",
-                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": traffic,
-                # what actually binds this kernel: VALU wave-instructions per launch from the committed
-                # SQ_INSTS_VALU pass over this launch duration, against one issue per SIMD per 4 clocks at 2.4 GHz
-                "valu_issue": ({"achieved": round(valu_instr / (avg_ms * 1e-3) / 1e9, 1), "peak": VALU_ISSUE_PEAK_G,
-                                "unit": "G wave-instructions/s", "frac": round(valu_instr / (avg_ms * 1e-3) / 1e9 / VALU_ISSUE_PEAK_G, 4)}
-                               if valu_instr and avg_ms > 0 else None),
-                "algorithmic_bytes_per_launch": int(per_launch_bytes), "avg_launch_ms": round(avg_ms, 4),
-                "launches_timed": launches,
-                "per_ray": {"node_visits": round(cst["node_visits"] / max(1, n_near), 2),
-                            "box_tests": round(cst["box_tests"] / max(1, n_near), 2),
-                            "tri_tests": round(cst["tri_tests"] / max(1, n_near), 2),
-                            "bytes": round(bytes_near / max(1, n_near), 1)},
-                "per_shadow_ray": {"node_visits": round(cst["node_visits_shadow"] / max(1, cst["rays_shadow"]), 2),
-                                   "box_tests": round(cst["box_tests_shadow"] / max(1, cst["rays_shadow"]), 2),
-                                   "tri_tests": round(cst["tri_tests_shadow"] / max(1, cst["rays_shadow"]), 2),
-                                   "bytes": round(bytes_shadow / max(1, cst["rays_shadow"]), 1)},
-            },
+            "roofline": roof,
         }
+        if per_rank is not None:
+            out["config"]["per_rank_ms"] = {"columns": ["device_render", "host_render_call", "tile_pack", "gather", "unpack"], "ranks": per_rank}
         if world == 1:
             # the PCIe-inclusive frame (crt_render: same kernels + device->host copy of the BGR frame);
             # reported beside, never as, `value`
@@ -291,16 +421,15 @@ def main():
                 ctx.render(cam, tgt, params)
             out["config"]["frame_ms_with_d2h_copy"] = round((time.perf_counter() - t1) / 3 * 1e3, 4)
         if a.out_bmp and world == 1:
-            crt.write_bmp(a.out_bmp, ctx.render(cam, tgt, params), a.width, a.height)
+            crt.write_bmp(a.out_bmp, ctx.render(cam, tgt, params), fw, fh)
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(prims, lights, cam, tgt, a.width, a.height, a.bounces, a.cpu_threads)
+            out["cpu_baseline"] = cpu_baseline(prims, lights, cam, tgt, fw, fh, a.bounces, a.cpu_threads)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    _ = rays_local
 
 
 if __name__ == "__main__":

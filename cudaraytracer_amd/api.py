@@ -55,7 +55,13 @@ class Stats(C.Structure):
                 ("nodes", C.c_int32), ("prims", C.c_int32), ("depth", C.c_int32), ("leaves", C.c_int32),
                 ("ms_build_host", C.c_double), ("ms_refit", C.c_double), ("scene_bytes", C.c_uint64),
                 ("node_visits", C.c_uint64), ("node_visits_shadow", C.c_uint64), ("ms_build_device", C.c_double),
-                ("ms_trace_mixed", C.c_double), ("launches_trace_mixed", C.c_int32), ("pad_", C.c_int32)]
+                ("ms_trace_mixed", C.c_double), ("launches_trace_mixed", C.c_int32), ("pad_", C.c_int32),
+                ("sched_iterations", C.c_uint64), ("sched_node_iterations", C.c_uint64), ("sched_node_lanes", C.c_uint64),
+                ("sched_prim_iterations", C.c_uint64), ("sched_prim_lanes", C.c_uint64), ("sched_active_lanes", C.c_uint64),
+                ("sched_refill_iterations", C.c_uint64), ("sched_finish_iterations", C.c_uint64),
+                ("sched_setup_iterations", C.c_uint64),
+                ("sched_pop_iterations", C.c_uint64), ("sched_decode_iterations", C.c_uint64), ("sched_hit_iterations", C.c_uint64),
+                ("visits_no_child_hit", C.c_uint64), ("trace_waves", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -427,6 +427,10 @@ CRT_DEV void slab8(uint32_t& raw, uint32_t wnx, uint32_t wfx, uint32_t wny, uint
 #undef SLAB8_OPERANDS
 }
 
+/* region markers: comment lines in the generated assembly (no instruction, no clobber) that tools/isa_mix.py uses to
+ * attribute the kernel's instructions to the parts of an iteration */
+#define CRT_MARK(NAME) asm volatile("; CRT_MARK " NAME);
+
 #if CRT_TRACE8_MIN_WAVES > 0
 #define CRT_TRACE8_BOUNDS __launch_bounds__(kTraceBlock, CRT_TRACE8_MIN_WAVES)
 #else
@@ -477,8 +481,11 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
     uint32_t lkind = kShadowDirectional;   /* shadow lanes: float bits of the ray's light distance (kernels.h) */
     unsigned long long nbox[2] = {0, 0}, ntri[2] = {0, 0}, nsph[2] = {0, 0}, nvis[2] = {0, 0};      /* [0] nearest-hit rays, [1] shadow rays */
     unsigned long long sch[5] = {0, 0, 0, 0, 0}, nzero = 0, nstale = 0, nfound = 0;
+    unsigned long long itc[8] = {0, 0, 0, 0, 0, 0, 0, 0};      /* wave-level iterations: all, with a refill fetch, with a finishing lane, with a ray set-up,
+                                                                 * node steps with a stack pop, primitive steps with a leaf decode, with a hit */
 
     for (;;) {
+        CRT_MARK("refill1_begin")
         /* ---- refill, first half: when enough lanes are idle, take rays off the queue and ISSUE their
          *      loads; the set-up runs after this iteration's traversal step, whose own node / primitive
          *      loads return later (loads return in order), so the refill costs the wave no extra stall ---- */
@@ -488,6 +495,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
             const unsigned long long idle = __ballot(!active);
             const int nidle = __popcll(idle);
             if (nidle >= kRefillMinIdle8) {
+                if (COUNT && lane == 0) itc[1]++;
                 if (cnext >= cend) {
                     bool got = false;
                     while (region_k < 8 && !got) {
@@ -539,7 +547,10 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                 }
             }
         }
+        CRT_MARK("refill1_end")
+        if (COUNT && lane == 0) itc[0]++;
         if (__ballot(active) != 0ull) {
+            CRT_MARK("vote_begin")
             const bool want_prim = active && (lp < lend || plm >= (1u << 24));
             const bool want_node = active && !want_prim;
             const int n_node = __popcll(__ballot(want_node));
@@ -549,8 +560,12 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                 if (n_node * CRT_VOTE8_PRIM_WEIGHT >= n_prim * CRT_VOTE8_NODE_WEIGHT) { sch[0]++; sch[1] += n_node; } else { sch[2]++; sch[3] += n_prim; }
                 sch[4] += n_node + n_prim;
             }
+            CRT_MARK("vote_end")
             if (n_node * CRT_VOTE8_PRIM_WEIGHT >= n_prim * CRT_VOTE8_NODE_WEIGHT) {
+                CRT_MARK("node_begin")
                 if (want_node) {
+                    if (COUNT) { const bool any_ = __ballot((gmask & 0xffu) == 0u) != 0ull; if (lane == 0 && any_) itc[4]++; }
+                    CRT_MARK("pop_begin")
                     if ((gmask & 0xffu) == 0u) {
                         if (sp == 0) finish = true;
                         else {
@@ -562,6 +577,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                             gbase = e.x; gmask = e.y;
                         }
                     }
+                    CRT_MARK("pop_end")
                     if (!finish) {
                         const uint32_t pbit = 31u - (uint32_t)__clz((int)(gmask & 0xffu));
                         const uint32_t slot = pbit ^ R;
@@ -620,8 +636,12 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                         if (raw == 0u && sp == 0) finish = true;
                     }
                 }
+                CRT_MARK("node_end")
             } else {
+                CRT_MARK("prim_begin")
                 if (want_prim) {
+                    if (COUNT) { const bool any_ = __ballot(lp == lend) != 0ull; if (lane == 0 && any_) itc[5]++; }
+                    CRT_MARK("decode_begin")
                     if (lp == lend) {
                         const uint32_t k = (uint32_t)__ffs((int)(plm >> 24)) - 1u;
                         plm &= ~(1u << (24u + k));
@@ -629,13 +649,16 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                         lp = (plm & 0xffffffu) + (m & 31u);
                         lend = lp + ((m >> 5) & 3u) + 1u;
                     }
+                    CRT_MARK("decode_end")
                     const uint32_t p = lp++;
                     const GeomRec g = load_geom(A.sv.geom, p);
                     float t = 0.f, tsm;
                     bool hit;
                     const bool shray = (ray >> 31) != 0u;
-                    if (is_sphere(g)) { if (COUNT) nsph[shray]++; hit = sphere_test(g, o, d, t, tsm); }
+                    if (is_sphere(g)) { CRT_MARK("sphere_begin") if (COUNT) nsph[shray]++; hit = sphere_test(g, o, d, t, tsm); CRT_MARK("sphere_end") }
                     else { if (COUNT) ntri[shray]++; hit = tri_test(g, o, d, tbest, t); }
+                    if (COUNT) { const bool any_ = __ballot(hit) != 0ull; if (lane == 0 && any_) itc[6]++; }
+                    CRT_MARK("hit_begin")
                     if (hit) {
                         if (!shray) {
                             if (t < tbest || (t == tbest && best >= 0 && A.sv.rank[p] < A.sv.rank[best])) { tbest = t; best = (int)p; }
@@ -671,9 +694,13 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                             }
                         }
                     }
+                    CRT_MARK("hit_end")
                     if (lp == lend && plm < (1u << 24) && (gmask & 0xffu) == 0u && sp == 0) finish = true;
                 }
+                CRT_MARK("prim_end")
             }
+            CRT_MARK("finish_begin")
+            if (COUNT) { const bool any_ = __ballot(finish) != 0ull; if (lane == 0 && any_) itc[2]++; }
             if (finish) {
                 if (!(ray >> 31)) {
                     A.hitSlot[ray] = best;
@@ -696,7 +723,10 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                 }
                 active = false; lp = lend = 0; plm = 0;
             }
+            CRT_MARK("finish_end")
         }
+        CRT_MARK("refill2_begin")
+        if (COUNT) { const bool any_ = __ballot(pend) != 0ull; if (lane == 0 && any_) itc[3]++; }
         /* ---- refill, second half: ray set-up for the lanes whose loads were issued above ---- */
         if (pend) {
             const float4 ro = pro4, rd = prd;
@@ -731,6 +761,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                 active = true;
             }
         }
+        CRT_MARK("refill2_end")
         if (exhausted && __ballot(active) == 0ull) break;
     }
     if (COUNT) {
@@ -744,6 +775,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
         atomicAdd(&A.counters[13], nzero);
         atomicAdd(&A.counters[14], nstale);      /* node visits of shadow rays that already hold a hit with t > 1e-9 */
         atomicAdd(&A.counters[15], nfound);
+        if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&A.counters[20 + i], itc[i]);
     }
 }
 

@@ -168,14 +168,21 @@ class ShardedRenderer:
             self.gathered = [torch.zeros(mx, dtype=torch.uint8, device=self.dev) for _ in range(self.world)] \
                 if self.rank == 0 else None
 
-    def render(self, cam, target, params):
-        """Render this rank's tiles, gather to rank 0.  Returns the device frame tensor on rank 0."""
+    def render(self, cam, target, params, phase=None):
+        """Render this rank's tiles, gather to rank 0.  Returns the device frame tensor on rank 0.
+        `phase` (optional dict) accumulates this rank's wall seconds per phase: render, pack, gather, unpack."""
+        import time
         params.rank, params.nranks = self.rank, self.world
         self._ensure(params)
-        self.ctx.render_device(cam, target, params, self.frame.data_ptr())
+        t0 = time.perf_counter()
+        self.ctx.render_device(cam, target, params, self.frame.data_ptr())       # returns with the frame complete
+        t1 = time.perf_counter()
+        if phase is not None:
+            phase["render"] = phase.get("render", 0.0) + (t1 - t0)
         if self.world == 1:
             return self.frame
-        self.ctx.tiles_pack(params, self.frame.data_ptr(), self.packed.data_ptr())
+        self.ctx.tiles_pack(params, self.frame.data_ptr(), self.packed.data_ptr())     # returns with the copy finished
+        t2 = time.perf_counter()
         if self.host_gather:
             mine = self.packed.cpu()
             got = [self.torch.zeros_like(mine) for _ in range(self.world)] if self.rank == 0 else None
@@ -187,9 +194,13 @@ class ShardedRenderer:
             self.dist.gather(self.packed, self.gathered, dst=0)
         # every rank waits for its part of the gather: the next frame packs into the same buffer on another stream
         self.torch.cuda.synchronize(self.dev)
+        t3 = time.perf_counter()
         if self.rank == 0:
             for r in range(1, self.world):
                 self.ctx.tiles_unpack(params, r, self.gathered[r].data_ptr(), self.frame.data_ptr())
             self.ctx.sync()
-            return self.frame
-        return None
+        if phase is not None:
+            phase["pack"] = phase.get("pack", 0.0) + (t2 - t1)
+            phase["gather"] = phase.get("gather", 0.0) + (t3 - t2)
+            phase["unpack"] = phase.get("unpack", 0.0) + (time.perf_counter() - t3)
+        return self.frame if self.rank == 0 else None

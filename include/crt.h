@@ -102,6 +102,17 @@ typedef struct crt_stats {
      * launches are counted here, the pure ones (primary rays; last bounce's shadow rays) in the fields above */
     double ms_trace_mixed;
     int32_t launches_trace_mixed, pad_;
+    /* counting only, wide path: what the persistent waves of k_trace8 did, summed over the frame's launches.  An
+     * iteration of a wave is either a node step (every lane that wants one tests the 8 children of its node) or a
+     * primitive step (one primitive per lane); bench.py prices them with tools/isa_mix.py's per-region instruction counts */
+    uint64_t sched_iterations;          /* loop iterations of all waves */
+    uint64_t sched_node_iterations, sched_node_lanes;    /* node steps and the lanes they served */
+    uint64_t sched_prim_iterations, sched_prim_lanes;
+    uint64_t sched_active_lanes;        /* lanes holding a ray, summed over iterations */
+    uint64_t sched_refill_iterations, sched_finish_iterations, sched_setup_iterations;
+    uint64_t sched_pop_iterations, sched_decode_iterations, sched_hit_iterations;   /* node steps with a stack pop; primitive steps with a leaf decode / with a hit */
+    uint64_t visits_no_child_hit;       /* node visits whose 8 slab tests all failed */
+    uint64_t trace_waves;               /* waves launched by the traversal launches (persistent grid x launches) */
 } crt_stats;
 
 typedef struct crt_ctx crt_ctx;

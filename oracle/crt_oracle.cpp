@@ -333,7 +333,7 @@ static uint32_t area_hash(uint32_t pixel, uint32_t light, uint32_t bounce, uint3
 }
 
 void shade(const orc_scene* sc, IsectS& is, const orc_light* lights, int numlights, bool live, Counters& k,
-           int lightSamples = 30, uint32_t pixel = 0, uint32_t bounce = 0) {
+           int lightSamples = 30, uint32_t pixel = 0, uint32_t bounce = 0, uint32_t sample = 0) {
     const float RAY_EPSILON = 0.000000001f;
     ov3 color;
     ov3 direction = onormalize(is.incidentDirection);
@@ -350,7 +350,7 @@ void shade(const orc_scene* sc, IsectS& is, const orc_light* lights, int numligh
              * l.position cumulatively, a random walk); the light is skipped by the point/directional branches
              * below (the block falls through into them). */
             const float* tab = area_table_get();
-            const uint32_t h = area_hash(pixel, (uint32_t)j, bounce, 0u);
+            const uint32_t h = area_hash(pixel, (uint32_t)j, bounce, sample);
             ov3 avgcolor;
             for (int si = 0; si < lightSamples; si++) {
                 const float* e = tab + 3 * ((h + (uint32_t)si) & (uint32_t)(kAreaTableN - 1));
@@ -437,9 +437,18 @@ Camera make_camera(const ov3& cameraPosition, const ov3& cameraDirection, float 
     return c;
 }
 /* Ray.cu:31-52 GeneratePrimaryRays, one pixel (literal 720 generalised to width) */
-void primary_ray(const Camera& c, int i, int width, RayS& r) {
+/* spp_n > 1: sub-sample `sample` of an spp_n x spp_n stratified grid, offsets ((k + .5) / spp_n - .5) along u and v
+ * (SURVEY.md 8(d) config 5).  The reference has no supersampling (Ray.cu:26,28,41-42 are stubs): an extension, restated
+ * here so that spp > 1 frames have an oracle; spp_n <= 1 is Ray.cu:31-52 untouched. */
+void primary_ray(const Camera& c, int i, int width, RayS& r, int spp_n = 1, int smp = 0) {
     int ipix = i % width, jpix = i / width;
-    ov3 pix = (c.L + c.u * float(ipix) + c.v * float(jpix));
+    ov3 pix;
+    if (spp_n <= 1) pix = (c.L + c.u * float(ipix) + c.v * float(jpix));
+    else {
+        const float ox = ((float)(smp % spp_n) + .5f) / (float)spp_n - .5f;
+        const float oy = ((float)(smp / spp_n) + .5f) / (float)spp_n - .5f;
+        pix = (c.L + c.u * (float(ipix) + ox) + c.v * (float(jpix) + oy));
+    }
     float xoffset = 0, yoffset = 0;
     ov3 sample = onormalize(ov3(pix.x + xoffset, pix.y + yoffset, pix.z) - c.pos);
     r.raytype = 0; r.position = c.pos; r.direction = sample; r.surfaceReflectiveCoef = ov3(0, 0, 0);
@@ -824,7 +833,16 @@ void orc_area_table(float* out3, int n) { area_table(out3, n); }
 int orc_render_area(orc_scene* s, const orc_light* lights, int nlights, const float cam[3], const float target[3],
                     int width, int height, int bounces, const int32_t* rect, unsigned char* bgr, float* color_f32,
                     int32_t* ids, float* ts, int nthreads, int area_samples) {
+    return orc_render_spp(s, lights, nlights, cam, target, width, height, bounces, rect, bgr, color_f32, ids, ts, nthreads, area_samples, 1);
+}
+
+/* spp_n x spp_n stratified samples per pixel: every sample is one full path as below; the float colours are summed in
+ * sample order and divided by spp_n^2 before Ray.cu:724-731.  ids / ts report the LAST sample's hits. */
+int orc_render_spp(orc_scene* s, const orc_light* lights, int nlights, const float cam[3], const float target[3],
+                   int width, int height, int bounces, const int32_t* rect, unsigned char* bgr, float* color_f32,
+                   int32_t* ids, float* ts, int nthreads, int area_samples, int spp_n) {
     if (!s->root) return -1;
+    if (spp_n < 1) spp_n = 1;
     Camera c = make_camera(ov3(cam), ov3(target), (float)width, (float)height);
     int x0 = 0, y0 = 0, x1 = width, y1 = height;
     if (rect) { x0 = rect[0]; y0 = rect[1]; x1 = rect[2]; y1 = rect[3]; }
@@ -835,8 +853,11 @@ int orc_render_area(orc_scene* s, const orc_light* lights, int nlights, const fl
         Counters& k = ks[t];
         for (int q = b; q < e; q++) {
             int i = (y0 + q / rw) * width + (x0 + q % rw);
+            ov3 sum;
+            ov3 col;
+            for (int smp = 0; smp < spp_n * spp_n; smp++) {
             RayS ray, refl; IsectS is;
-            primary_ray(c, i, width, ray);
+            primary_ray(c, i, width, ray, spp_n, smp);
             bool dead = false;
             for (int bn = 0; bn < bounces; bn++) {
                 if (dead) {
@@ -852,10 +873,13 @@ int orc_render_area(orc_scene* s, const orc_light* lights, int nlights, const fl
                 if (ids) ids[(size_t)bn * total + i] = id;
                 if (ts) ts[(size_t)bn * total + i] = tHit;
                 if (id == -1) { is.color = keep; dead = true; continue; }   /* G6: defined as path end */
-                shade(s, is, lights, nlights, live, k, area_samples, (uint32_t)i, (uint32_t)bn);
+                shade(s, is, lights, nlights, live, k, area_samples, (uint32_t)i, (uint32_t)bn, (uint32_t)smp);
                 ray = refl;
             }
-            ov3 col = is.color;
+            col = is.color;
+            if (spp_n > 1) { if (smp == 0) sum = ov3(0, 0, 0); sum = ov3(sum.x + col.x, sum.y + col.y, sum.z + col.z); }
+            }
+            if (spp_n > 1) { const float inv = (float)(spp_n * spp_n); col = ov3(sum.x / inv, sum.y / inv, sum.z / inv); }
             if (color_f32) col.store(color_f32 + 3 * (size_t)i);
             /* Ray.cu:724-731 */
             col = col * 255.0f;

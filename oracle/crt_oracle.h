@@ -105,6 +105,11 @@ int orc_render(orc_scene*, const orc_light* lights, int nlights, const float cam
 int orc_render_area(orc_scene*, const orc_light* lights, int nlights, const float cam[3], const float target[3],
                     int width, int height, int bounces, const int32_t* rect, unsigned char* bgr, float* color_f32,
                     int32_t* ids, float* ts, int nthreads, int area_samples);
+/* the same with spp_n x spp_n stratified sub-pixel samples per pixel (an extension: the reference's antialiasing
+ * globals are stubs, Ray.cu:26,28,41-42); spp_n = 1 is orc_render_area */
+int orc_render_spp(orc_scene*, const orc_light* lights, int nlights, const float cam[3], const float target[3],
+                   int width, int height, int bounces, const int32_t* rect, unsigned char* bgr, float* color_f32,
+                   int32_t* ids, float* ts, int nthreads, int area_samples, int spp_n);
 void orc_area_table(float* out3, int n);                   /* n <= 1024 entries (U1, cos(theta), sin(theta)) */
 void orc_primary_rays(const float cam[3], const float target[3], int width, int height, float* rays6);
 void orc_stats_get(orc_scene*, orc_stats* out);

@@ -60,6 +60,7 @@ def lib():
             "orc_tree_dump": [vp] * 9,
             "orc_render": [vp, vp, i, vp, vp, i, i, i, vp, vp, vp, vp, vp, i],
             "orc_render_area": [vp, vp, i, vp, vp, i, i, i, vp, vp, vp, vp, vp, i, i],
+            "orc_render_spp": [vp, vp, i, vp, vp, i, i, i, vp, vp, vp, vp, vp, i, i, i],
             "orc_load_obj": [C.c_char_p, vp, vp, i],
         }.items():
             getattr(L, name).restype = i
@@ -202,15 +203,17 @@ class Scene:
         return ids, ts
 
     def render(self, lights, cam, target, w, h, bounces, rect=None, nthreads=8, want_color=False, want_ids=False,
-               area_samples=30):
+               area_samples=30, spp=1):
+        spp_n = int(round(spp ** 0.5))
+        assert spp_n * spp_n == spp
         lights = np.ascontiguousarray(lights, LIGHT_DTYPE)
         bgr = np.zeros((h, w, 3), np.uint8)
         col = np.zeros((h * w, 3), np.float32) if want_color else None
         ids = np.zeros((bounces, h * w), np.int32) if want_ids else None
         ts = np.zeros((bounces, h * w), np.float32) if want_ids else None
         r = np.ascontiguousarray(rect, np.int32) if rect is not None else None
-        rc = lib().orc_render_area(self.h, _p(lights), len(lights), _p(f3(cam)), _p(f3(target)), w, h, bounces, _p(r),
-                                   _p(bgr), _p(col), _p(ids), _p(ts), nthreads, area_samples)
+        rc = lib().orc_render_spp(self.h, _p(lights), len(lights), _p(f3(cam)), _p(f3(target)), w, h, bounces, _p(r),
+                                  _p(bgr), _p(col), _p(ids), _p(ts), nthreads, area_samples, spp_n)
         assert rc == 0
         return dict(bgr=bgr, color=col, ids=ids, ts=ts)
 
