@@ -377,7 +377,9 @@ def main():
         if cst["sched_iterations"] > 0:
             roof["schedule"] = {"node_iterations": cst["sched_node_iterations"], "lanes_per_node_iteration": round(cst["sched_node_lanes"] / max(1, cst["sched_node_iterations"]), 1),
                                 "prim_iterations": cst["sched_prim_iterations"], "lanes_per_prim_iteration": round(cst["sched_prim_lanes"] / max(1, cst["sched_prim_iterations"]), 1),
-                                "visits_no_child_hit_frac": round(cst["visits_no_child_hit"] / max(1, visits), 3)}
+                                "visits_no_child_hit_frac": round(cst["visits_no_child_hit"] / max(1, visits), 3),
+                                "visits_no_child_hit_because_of_t_limit_frac": round(cst["visits_no_child_hit_tlimit"] / max(1, visits), 3),
+                                "child_boxes_rejected_by_t_limit_frac": round(cst["boxes_rejected_by_tlimit"] / max(1, cst["box_tests"] + cst["box_tests_shadow"]), 3)}
         scaling = "weak" if a.weak else "strong"      # N > 1 shards the same frame unless --weak
         out = {
             "metric": "Mrays/sec (primary+shadow+reflect), 1M-tri 4K scene" if a.config == 3 and not a.weak else

@@ -61,7 +61,8 @@ class Stats(C.Structure):
                 ("sched_refill_iterations", C.c_uint64), ("sched_finish_iterations", C.c_uint64),
                 ("sched_setup_iterations", C.c_uint64),
                 ("sched_pop_iterations", C.c_uint64), ("sched_decode_iterations", C.c_uint64), ("sched_hit_iterations", C.c_uint64),
-                ("visits_no_child_hit", C.c_uint64), ("trace_waves", C.c_uint64)]
+                ("visits_no_child_hit", C.c_uint64), ("visits_no_child_hit_tlimit", C.c_uint64), ("boxes_rejected_by_tlimit", C.c_uint64),
+                ("trace_waves", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

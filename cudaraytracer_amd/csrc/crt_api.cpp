@@ -972,7 +972,7 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
         st.box_tests = t[0]; st.tri_tests = t[1]; st.sph_tests = t[2]; st.node_visits = t[3];
         st.box_tests_shadow = t[16]; st.tri_tests_shadow = t[17]; st.sph_tests_shadow = t[18]; st.node_visits_shadow = t[19];
         st.sched_node_iterations = t[8]; st.sched_node_lanes = t[9]; st.sched_prim_iterations = t[10]; st.sched_prim_lanes = t[11];
-        st.sched_active_lanes = t[12]; st.visits_no_child_hit = t[13];
+        st.sched_active_lanes = t[12]; st.visits_no_child_hit = t[13]; st.visits_no_child_hit_tlimit = t[28]; st.boxes_rejected_by_tlimit = t[29];
         st.sched_iterations = t[20]; st.sched_refill_iterations = t[21]; st.sched_finish_iterations = t[22]; st.sched_setup_iterations = t[23];
         st.sched_pop_iterations = t[24]; st.sched_decode_iterations = t[25]; st.sched_hit_iterations = t[26];
         st.trace_waves = (uint64_t)(st.launches_trace_nearest + st.launches_trace_shadow + st.launches_trace_mixed) * (uint64_t)c->grid_blocks * (kTraceBlock / 64);

@@ -480,7 +480,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
     int found = 0;
     uint32_t lkind = kShadowDirectional;   /* shadow lanes: float bits of the ray's light distance (kernels.h) */
     unsigned long long nbox[2] = {0, 0}, ntri[2] = {0, 0}, nsph[2] = {0, 0}, nvis[2] = {0, 0};      /* [0] nearest-hit rays, [1] shadow rays */
-    unsigned long long sch[5] = {0, 0, 0, 0, 0}, nzero = 0, nstale = 0, nfound = 0;
+    unsigned long long sch[5] = {0, 0, 0, 0, 0}, nzero = 0, nstale = 0, nfound = 0, nzero_t = 0, nculled_t = 0;
     unsigned long long itc[8] = {0, 0, 0, 0, 0, 0, 0, 0};      /* wave-level iterations: all, with a refill fetch, with a finishing lane, with a ray set-up,
                                                                  * node steps with a stack pop, primitive steps with a leaf decode, with a hit */
 
@@ -612,23 +612,30 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                          * v_perm source is the constant 0x64 */
 #define PAIR01(W) __builtin_amdgcn_perm(0x64646464u, (W), 0x04010400u)
 #define PAIR23(W) __builtin_amdgcn_perm(0x64646464u, (W), 0x04030402u)
-#define SLAB8x4(NXW, FXW, NYW, FYW, NZW, FZW)                                                                 \
+#define SLAB8x4(RAW, TB, NXW, FXW, NYW, FYW, NZW, FZW)                                                                 \
     {                                                                                                         \
         const uint32_t c0 = PAIR23(NXW), c1 = PAIR23(FXW), c2 = PAIR23(NYW), c3 = PAIR23(FYW), c4 = PAIR23(NZW), c5 = PAIR23(FZW); \
-        slab8<true>(raw, c0, c1, c2, c3, c4, c5, sx, sy, sz, bnx, bfx, bny, bfy, bnz, bfz, tbest);            \
-        slab8<false>(raw, c0, c1, c2, c3, c4, c5, sx, sy, sz, bnx, bfx, bny, bfy, bnz, bfz, tbest);           \
+        slab8<true>(RAW, c0, c1, c2, c3, c4, c5, sx, sy, sz, bnx, bfx, bny, bfy, bnz, bfz, TB);            \
+        slab8<false>(RAW, c0, c1, c2, c3, c4, c5, sx, sy, sz, bnx, bfx, bny, bfy, bnz, bfz, TB);           \
         const uint32_t a0 = PAIR01(NXW), a1 = PAIR01(FXW), a2 = PAIR01(NYW), a3 = PAIR01(FYW), a4 = PAIR01(NZW), a5 = PAIR01(FZW); \
-        slab8<true>(raw, a0, a1, a2, a3, a4, a5, sx, sy, sz, bnx, bfx, bny, bfy, bnz, bfz, tbest);            \
-        slab8<false>(raw, a0, a1, a2, a3, a4, a5, sx, sy, sz, bnx, bfx, bny, bfy, bnz, bfz, tbest);           \
+        slab8<true>(RAW, a0, a1, a2, a3, a4, a5, sx, sy, sz, bnx, bfx, bny, bfy, bnz, bfz, TB);            \
+        slab8<false>(RAW, a0, a1, a2, a3, a4, a5, sx, sy, sz, bnx, bfx, bny, bfy, bnz, bfz, TB);           \
     }
-                        SLAB8x4(nx1, fx1, ny1, fy1, nz1, fz1)      /* children 7, 6, 5, 4 */
-                        SLAB8x4(nx0, fx0, ny0, fy0, nz0, fz0)      /* children 3, 2, 1, 0 */
+                        SLAB8x4(raw, tbest, nx1, fx1, ny1, fy1, nz1, fz1)      /* children 7, 6, 5, 4 */
+                        SLAB8x4(raw, tbest, nx0, fx0, ny0, fy0, nz0, fz0)      /* children 3, 2, 1, 0 */
+                        uint32_t raw_far = 0;            /* counting only: what the visit would have hit without the t limit */
+                        if (COUNT) {
+                            const float tinf = INFINITY;
+                            SLAB8x4(raw_far, tinf, nx1, fx1, ny1, fy1, nz1, fz1)
+                            SLAB8x4(raw_far, tinf, nx0, fx0, ny0, fy0, nz0, fz0)
+                        }
 #undef SLAB8x4
 #undef PAIR01
 #undef PAIR23
                         const uint32_t vmask = h1.x >> 24, imask = em >> 24;
                         raw &= vmask;                       /* an empty slot can pass the padded test of a degenerate node */
-                        if (COUNT) { nbox[ray >> 31] += (unsigned long long)__popc(vmask); nvis[ray >> 31]++; if (raw == 0u) nzero++; if ((ray >> 31) && found) nstale++; }
+                        if (COUNT) { nbox[ray >> 31] += (unsigned long long)__popc(vmask); nvis[ray >> 31]++; if (raw == 0u) nzero++; if ((ray >> 31) && found) nstale++;
+                                     if (raw == 0u && (raw_far & vmask) != 0u) nzero_t++; nculled_t += (unsigned long long)__popc(raw_far & vmask & ~raw); }
                         gbase = h1.x & 0xffffffu;
                         gmask = (imask << 8) | (uint32_t)s_perm[R][raw & imask];
                         plm = h1.y | ((raw & ~imask) << 24);
@@ -775,6 +782,8 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
         atomicAdd(&A.counters[13], nzero);
         atomicAdd(&A.counters[14], nstale);      /* node visits of shadow rays that already hold a hit with t > 1e-9 */
         atomicAdd(&A.counters[15], nfound);
+        atomicAdd(&A.counters[28], nzero_t);        /* visits that hit no child only because of the t limit (stale stack entries) */
+        atomicAdd(&A.counters[29], nculled_t);      /* child boxes the t limit rejected */
         if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&A.counters[20 + i], itc[i]);
     }
 }

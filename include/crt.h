@@ -112,6 +112,8 @@ typedef struct crt_stats {
     uint64_t sched_refill_iterations, sched_finish_iterations, sched_setup_iterations;
     uint64_t sched_pop_iterations, sched_decode_iterations, sched_hit_iterations;   /* node steps with a stack pop; primitive steps with a leaf decode / with a hit */
     uint64_t visits_no_child_hit;       /* node visits whose 8 slab tests all failed */
+    uint64_t visits_no_child_hit_tlimit; /* ... of which some child would have passed without the ray's current t limit (entries stacked before a nearer hit was found) */
+    uint64_t boxes_rejected_by_tlimit;
     uint64_t trace_waves;               /* waves launched by the traversal launches (persistent grid x launches) */
 } crt_stats;
 

@@ -50,7 +50,7 @@ def test_area_light_matches_oracle(crt, bvh_mode):
             sc.stats(reset=True)
             g = ctx.render(cam, tgt, crt.default_params(width=w, height=h, bounces=bounces, area_samples=samples))
             o = sc.render(lights, cam, tgt, w, h, bounces, nthreads=16, area_samples=samples)
-            check(g, o, f"area lights bvh={bvh_mode} samples={samples} {w}x{h} bounces={bounces}", max_bad=4)
+            check(g, o, f"area lights bvh={bvh_mode} samples={samples} {w}x{h} bounces={bounces}", max_bad=0)
             st = ctx.stats()
             live = sc.stats(reset=True)["live_traversals"]
             issued = st["rays_primary"] + st["rays_shadow"] + st["rays_reflect"]

@@ -38,5 +38,5 @@ def test_headless_demo_frames_match_oracle(tmp_path):
         want = sc.render(lights, cam, tgt, 720, 360, 2, nthreads=16)["bgr"]
         got = np.asarray(Image.open(f"{prefix}_{f:03d}.bmp").convert("RGB"))[::-1, :, ::-1]
         diff = np.abs(got.astype(np.int32) - want.astype(np.int32)).max(axis=2)
-        assert int((diff > 1).sum()) <= 2, f"frame {f}: {int((diff > 1).sum())} pixels beyond 1 LSB"
+        assert int((diff > 1).sum()) == 0, f"frame {f}: {int((diff > 1).sum())} pixels beyond 1 LSB"
         sc.animate()

@@ -105,7 +105,7 @@ def test_device_rebuild_in_the_animation_loop(crt):
                 g = ctx.render(cam, tgt, p)
                 o = sc.render(lights, cam, tgt, 320, 180, 3, nthreads=16)
                 diff = np.abs(g.astype(np.int32) - o["bgr"].astype(np.int32)).max(axis=2)
-                assert int((diff > 1).sum()) <= 4, f"frame {frame}: {int((diff > 1).sum())} pixels beyond 1 LSB"
+                assert int((diff > 1).sum()) == 0, f"frame {frame}: {int((diff > 1).sum())} pixels beyond 1 LSB"
     finally:
         ctx.close(); sc.close()
 

@@ -14,7 +14,10 @@ pytestmark = pytest.mark.gpu
 
 T_RTOL = 1e-4          # north_star: hit t within 1e-4 relative
 LSB = 1                # north_star: 8-bit colour within 1 LSB
-GRAZING_FRACTION = 2e-4  # bound on rays allowed in the stated exception classes
+# Both sides evaluate the reference's float expressions in the same order without contraction, and every run so far has
+# been exact, so the allowances are zero: an id flip, a t outside tolerance or a pixel beyond 1 LSB is a regression until
+# it has been assigned to one of SURVEY.md 9.1's classes (classify() below says which one a mismatch looks like).
+MAX_ID_MISMATCH = 0
 
 
 @pytest.fixture(scope="module")
@@ -37,6 +40,21 @@ def teapot(crt):
     sc.close()
 
 
+def classify(ids_g, ts_g, ids_o, ts_o, bad):
+    """What the first mismatches look like, in the vocabulary of SURVEY.md 9.1: G2 (both sides report a hit at the
+    bit-identical t: a tie resolved differently), G1/G3 (one side misses, or the t differ: a threshold or box-face case)."""
+    out = []
+    for i in np.flatnonzero(bad)[:8]:
+        if ids_g[i] >= 0 and ids_o[i] >= 0 and ts_g[i] == ts_o[i]:
+            cls = "G2 equal-t tie"
+        elif (ids_g[i] < 0) != (ids_o[i] < 0):
+            cls = "G1/G3 hit on one side only"
+        else:
+            cls = "G1 different t"
+        out.append(f"ray {i}: gpu ({ids_g[i]}, {ts_g[i]!r}) oracle ({ids_o[i]}, {ts_o[i]!r}) -> {cls}")
+    return "; ".join(out)
+
+
 def compare_hits(ids_g, ts_g, ids_o, ts_o, what):
     n = len(ids_o)
     bad_id = ids_g != ids_o
@@ -45,7 +63,7 @@ def compare_hits(ids_g, ts_g, ids_o, ts_o, what):
     n_t = int((rel > T_RTOL).sum())
     print(f"{what}: rays={n} hits={int((ids_o >= 0).sum())} id_mismatch={int(bad_id.sum())} "
           f"t_exact={int((ts_g[hit] == ts_o[hit]).sum())}/{int(hit.sum())} t_out_of_tol={n_t}")
-    assert bad_id.sum() <= max(2, GRAZING_FRACTION * n), f"{what}: {bad_id.sum()} nearest-hit id mismatches"
+    assert bad_id.sum() <= MAX_ID_MISMATCH, f"{what}: {bad_id.sum()} nearest-hit id mismatches: {classify(ids_g, ts_g, ids_o, ts_o, bad_id)}"
     assert n_t == 0, f"{what}: {n_t} hit distances beyond {T_RTOL} relative"
     return int(bad_id.sum())
 
@@ -100,7 +118,7 @@ def test_shadow_predicate(crt, teapot):
     want = ((ids_o >= 0) & (ts_o > np.float32(1e-9))).astype(np.uint8)    # Ray.cu:652-656
     got = ctx.trace_shadow(rays)
     assert want.sum() > 1000
-    assert int((want != got).sum()) <= 2, f"{int((want != got).sum())} shadow predicate mismatches"
+    assert int((want != got).sum()) == 0, f"{int((want != got).sum())} shadow predicate mismatches"
 
 
 def render_pair(crt, ctx, sc, w, h, bounces, lights):
@@ -148,7 +166,7 @@ def test_render_teapot_1080p_depth3(crt, teapot):
     """configs[1]: teapot3.obj 1920x1080, reflection depth 3 (bounces=4)."""
     prims, ctx, sc = teapot
     g, o, p = render_pair(crt, ctx, sc, 1920, 1080, 4, crt.default_lights())
-    check_image(g, o, "teapot 1920x1080 bounces=4", max_bad=8)
+    check_image(g, o, "teapot 1920x1080 bounces=4", max_bad=0)
     sc.stats(reset=True)
 
 
@@ -163,7 +181,7 @@ def test_point_light_and_odd_size(crt, teapot):
     ctx.set_lights(lights)
     try:
         g, o, p = render_pair(crt, ctx, sc, 333, 205, 3, lights)   # not a multiple of the 32x32 tile
-        check_image(g, o, "point light 333x205 bounces=3", max_bad=4)
+        check_image(g, o, "point light 333x205 bounces=3", max_bad=0)
         # the same through the reference topology (k_trace<SHADOW> takes the light's distance from the ray record too)
         ctx1 = crt.Context(0)
         try:
@@ -171,7 +189,7 @@ def test_point_light_and_odd_size(crt, teapot):
             g1 = ctx1.render(crt.default_camera()[0], crt.default_camera()[1], p)
         finally:
             ctx1.close()
-        check_image(g1, o, "point light 333x205 bounces=3, reference topology", max_bad=4)
+        check_image(g1, o, "point light 333x205 bounces=3, reference topology", max_bad=0)
     finally:
         ctx.set_lights(crt.default_lights())
         sc.stats(reset=True)
@@ -196,7 +214,7 @@ def test_no_lights_and_eight_lights(crt, teapot):
                 many[k]["constantTerm"] = 0.25; many[k]["linearTerm"] = 0.003372407; many[k]["quadraticTerm"] = 0.000045492
         ctx.set_lights(many)
         g, o, p = render_pair(crt, ctx, sc, 300, 200, 2, many)
-        check_image(g, o, "eight lights 300x200 bounces=2", max_bad=4)
+        check_image(g, o, "eight lights 300x200 bounces=2", max_bad=0)
     finally:
         ctx.set_lights(crt.default_lights())
         sc.stats(reset=True)
@@ -224,7 +242,7 @@ def test_spheres_scene_and_refit(crt):
             if frame in (0, 1, 5, 19, 20, 22):
                 g = ctx.render(cam, tgt, p)
                 o = sc.render(lights, cam, tgt, 480, 270, 2, nthreads=16)
-                check_image(g, o, f"spheres frame {frame}", max_bad=6)
+                check_image(g, o, f"spheres frame {frame}", max_bad=0)
     finally:
         ctx.close(); sc.close()
 
@@ -253,7 +271,7 @@ def test_device_animation_equals_host(crt):
                 assert ctx.get_scene().tobytes() == host.tobytes(), f"frame {frame}: device animation differs from the host step"
                 g = ctx.render(cam, tgt, p)
                 o = sc.render(lights, cam, tgt, 320, 180, 2, nthreads=16)
-                check_image(g, o, f"device-animated frame {frame}", max_bad=4)
+                check_image(g, o, f"device-animated frame {frame}", max_bad=0)
     finally:
         ctx.close(); sc.close()
 
@@ -334,3 +352,42 @@ def test_soup_small_image_parity(crt):
         check_image(g, o, "soup 30k 640x360 bounces=3", max_bad=bad)
     finally:
         ctx.close(); sc.close()
+
+
+def test_equal_t_ties_resolve_to_the_reference_order(crt):
+    """two primitives returning the bit-identical t -- the reference keeps the one its DFS meets first
+    (strict '<', Ray.cu:199,216).  Duplicated geometry makes every hit a tie: three coincident copies of the teapot's
+    triangles (the third in shuffled scene order) and of the sphere; at most 3 centroids coincide, so the reference's
+    split still terminates.  Coincident copies always share a reference leaf, whose order is the scene order (stable
+    partition, bvh.cu:58-68), so the reference's winner is the copy with the lowest scene index -- which is also what
+    a brute-force loop in scene order keeps.  Ids, t and the image must equal the oracle's on every tree the library
+    builds: the wide tree breaks ties by reference rank, the device-built one by scene index."""
+    base = crt.scene_teapot(with_sphere=True)
+    rng = np.random.default_rng(3)
+    prims = np.concatenate([base, base, base[rng.permutation(len(base))]])
+    sc = orc.Scene(prims); sc.build()
+    cam, tgt = crt.default_camera()
+    o = rng.uniform(-120, 120, (60000, 3)).astype(np.float32)
+    d = rng.uniform(-35, 35, (60000, 3)).astype(np.float32) - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([orc.primary_rays(cam, tgt, 360, 180), np.concatenate([o, d.astype(np.float32)], axis=1)]).astype(np.float32)
+    ids_o, ts_o = sc.trace(rays)
+    ids_b, ts_b = sc.trace_brute(rays)
+    hits = ids_o >= 0
+    assert hits.sum() > 20000
+    assert np.array_equal(ids_o, ids_b) and np.array_equal(ts_b.view(np.uint32)[hits], ts_o.view(np.uint32)[hits])
+    assert (ids_o[hits] < len(base)).all()          # the first copy wins every tie
+    lights = crt.default_lights()
+    want = sc.render(lights, cam, tgt, 360, 180, 3, nthreads=8)["bgr"]
+    sc.close()
+    for mode in (0, 1, 2):
+        ctx = crt.Context(0)
+        try:
+            ctx.set_scene(prims); ctx.set_lights(lights); ctx.build(mode)
+            ids_g, ts_g = ctx.trace(rays)
+            assert np.array_equal(ids_g, ids_o), f"mode {mode}: {classify(ids_g, ts_g, ids_o, ts_o, ids_g != ids_o)}"
+            assert np.array_equal(ts_g.view(np.uint32)[hits], ts_o.view(np.uint32)[hits])
+            got = ctx.render(cam, tgt, crt.default_params(width=360, height=180, bounces=3))
+            assert np.array_equal(got, want), f"mode {mode}: image differs on the all-ties scene"
+        finally:
+            ctx.close()
