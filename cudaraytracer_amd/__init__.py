@@ -7,7 +7,7 @@ has no compute of its own and no CPU fallback: if the library is missing, import
 ``cudaraytracer_amd.api`` raises.
 """
 from .api import (  # noqa: F401
-    Context, CrtError, PRIM_DTYPE, LIGHT_DTYPE, lib, lib_path, default_params, default_camera,
+    Context, MultiGpu, CrtError, PRIM_DTYPE, LIGHT_DTYPE, lib, lib_path, default_params, default_camera,
     default_lights, scene_teapot, scene_spheres, scene_soup, animate_host, load_obj, tiles_owned,
     tile_owner, write_bmp, host_bvh, area_table, TEAPOT_OBJ,
 )

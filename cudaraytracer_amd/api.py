@@ -78,6 +78,8 @@ ABI_SYMBOLS = [
     "crt_blob_size", "crt_blob_device_ptr", "crt_blob_import_device",
     "crt_tile_owner", "crt_tiles_owned", "crt_tiles_pack", "crt_tiles_unpack",
     "crt_get_stats", "crt_sync",
+    "crt_mgpu_create", "crt_mgpu_destroy", "crt_mgpu_size", "crt_mgpu_uses_rccl", "crt_mgpu_ctx", "crt_mgpu_last_error",
+    "crt_mgpu_lights_set", "crt_mgpu_sync_scene", "crt_mgpu_render", "crt_mgpu_render_device", "crt_mgpu_get_times",
     "crt_load_obj", "crt_scene_teapot", "crt_scene_spheres", "crt_scene_soup", "crt_lights_default", "crt_area_table",
     "crt_camera_default", "crt_animate_host", "crt_write_bmp", "crt_host_bvh",
 ]
@@ -113,6 +115,24 @@ for _name, _args in {
     "crt_scene_spheres": [_i, C.c_uint32, _vp], "crt_scene_soup": [_i, C.c_uint32, _vp],
     "crt_host_bvh": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i],
     "crt_lights_default": [_vp], "crt_area_table": [_vp, _i], "crt_animate_host": [_vp, _i], "crt_write_bmp": [C.c_char_p, _vp, _i, _i],
+}.items():
+    getattr(lib, _name).restype = _i
+    getattr(lib, _name).argtypes = _args
+
+
+lib.crt_mgpu_create.restype = _vp
+lib.crt_mgpu_create.argtypes = [_vp, _i, _i, C.POINTER(_i)]
+lib.crt_mgpu_destroy.restype = None
+lib.crt_mgpu_destroy.argtypes = [_vp]
+lib.crt_mgpu_ctx.restype = _vp
+lib.crt_mgpu_ctx.argtypes = [_vp, _i]
+lib.crt_mgpu_last_error.restype = C.c_char_p
+lib.crt_mgpu_last_error.argtypes = [_vp]
+for _name, _args in {
+    "crt_mgpu_size": [_vp], "crt_mgpu_uses_rccl": [_vp], "crt_mgpu_lights_set": [_vp, _vp, _i], "crt_mgpu_sync_scene": [_vp],
+    "crt_mgpu_render": [_vp, C.POINTER(Camera), C.POINTER(Params), _vp],
+    "crt_mgpu_render_device": [_vp, C.POINTER(Camera), C.POINTER(Params), C.POINTER(_vp)],
+    "crt_mgpu_get_times": [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)],
 }.items():
     getattr(lib, _name).restype = _i
     getattr(lib, _name).argtypes = _args
@@ -405,3 +425,66 @@ class Context:
 
     def sync(self):
         self._ck(lib.crt_sync(self.h))
+
+
+class MultiGpu:
+    """crt_mgpu: one process, one context per GPU, RCCL broadcast of the scene and gather of the tiles (mgpu.cpp)."""
+
+    def __init__(self, devices=None, rccl_always=False):
+        err = _i(0)
+        arr = (C.c_int * len(devices))(*devices) if devices else None
+        self.h = lib.crt_mgpu_create(arr, len(devices) if devices else 0, 1 if rccl_always else 0, C.byref(err))
+        if not self.h:
+            raise CrtError(err.value, "crt_mgpu_create failed")
+        self.size = lib.crt_mgpu_size(self.h)
+        self.uses_rccl = bool(lib.crt_mgpu_uses_rccl(self.h))
+        self.root = Context.__new__(Context)           # a view of rank 0's context: owned by the crt_mgpu
+        self.root.h = lib.crt_mgpu_ctx(self.h, 0)
+        self.root.nprims = 0
+        self.root.close = lambda: None
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise CrtError(rc, lib.crt_mgpu_last_error(self.h).decode())
+
+    def rank_stats(self, rank):
+        s = Stats()
+        rc = lib.crt_get_stats(lib.crt_mgpu_ctx(self.h, rank), C.byref(s))
+        if rc:
+            raise CrtError(rc, "crt_get_stats")
+        return s.as_dict()
+
+    def set_lights(self, lights):
+        lights = np.ascontiguousarray(lights, LIGHT_DTYPE)
+        self._ck(lib.crt_mgpu_lights_set(self.h, _ptr(lights), len(lights)))
+
+    def sync_scene(self):
+        self._ck(lib.crt_mgpu_sync_scene(self.h))
+
+    def render(self, cam, target, params):
+        out = np.zeros((params.height, params.width, 3), np.uint8)
+        c = Context._cam(cam, target)
+        self._ck(lib.crt_mgpu_render(self.h, C.byref(c), C.byref(params), _ptr(out)))
+        return out
+
+    def render_device(self, cam, target, params):
+        c = Context._cam(cam, target)
+        p = _vp(0)
+        self._ck(lib.crt_mgpu_render_device(self.h, C.byref(c), C.byref(params), C.byref(p)))
+        return p.value
+
+    def times(self):
+        a, b, c = C.c_double(0), C.c_double(0), C.c_double(0)
+        self._ck(lib.crt_mgpu_get_times(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"ms_render": a.value, "ms_exchange": b.value, "ms_unpack": c.value}
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.crt_mgpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -5,6 +5,7 @@
 #include "objloader.hpp"
 #include "../../../include/crt.h"
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <map>
@@ -13,7 +14,8 @@
 int numBounces = 2;
 
 namespace {
-crt_ctx* g_ctx = nullptr;
+crt_mgpu* g_mgpu = nullptr;                  /* every visible GPU (CRT_GPUS=n limits it): rank 0 owns the scene */
+crt_ctx* g_ctx = nullptr;                    /* = crt_mgpu_ctx(g_mgpu, 0) */
 std::string g_err;
 std::vector<SceneObject*> g_scene;          /* objects of the tree built last, in scene order */
 std::vector<Node*> g_nodes;                 /* ownership of the host Node tree */
@@ -21,14 +23,27 @@ std::vector<Node*> g_nodes;                 /* ownership of the host Node tree *
 crt_ctx* ctx() {
     if (!g_ctx) {
         int err = 0;
-        g_ctx = crt_create(0, &err);
-        if (!g_ctx) g_err = "crt_create failed (no HIP device?)";
+        /* the reference is single-GPU; here the frame's tiles are sharded over all GPUs of the node (RCCL broadcast of the
+         * scene, tile gather to GPU 0).  CRT_GPUS=n uses the first n devices; with one GPU no communicator is created */
+        int want = 0;
+        if (const char* e = getenv("CRT_GPUS")) want = atoi(e);
+        std::vector<int> devs;
+        for (int d = 0; d < want; d++) devs.push_back(d);
+        g_mgpu = crt_mgpu_create(devs.empty() ? nullptr : devs.data(), (int)devs.size(), 0, &err);
+        if (g_mgpu) g_ctx = crt_mgpu_ctx(g_mgpu, 0);
+        if (!g_ctx) g_err = "crt_mgpu_create failed (no HIP device?)";
     }
     return g_ctx;
 }
 bool ok(int rc, const char* what) {
     if (rc == CRT_OK) { g_err.clear(); return true; }
     g_err = std::string(what) + ": " + (g_ctx ? crt_last_error(g_ctx) : "no context");
+    fprintf(stderr, "%s\n", g_err.c_str());
+    return false;
+}
+bool okm(int rc, const char* what) {
+    if (rc == CRT_OK) { g_err.clear(); return true; }
+    g_err = std::string(what) + ": " + crt_mgpu_last_error(g_mgpu);
     fprintf(stderr, "%s\n", g_err.c_str());
     return false;
 }
@@ -87,6 +102,7 @@ Node* constructTree(std::vector<SceneObject*>& objects, Node*& currentNode, std:
     const int n = (int)prims.size();
     if (!ok(crt_scene_set(g_ctx, prims.data(), n), "constructTree/crt_scene_set")) return currentNode;
     if (!ok(crt_bvh_build(g_ctx, CRT_BVH_WIDE), "constructTree/crt_bvh_build")) return currentNode;
+    if (!okm(crt_mgpu_sync_scene(g_mgpu), "constructTree/crt_mgpu_sync_scene")) return currentNode;
     g_scene = objects;
     /* reference-shaped host tree for callers that walk it */
     int32_t nn = 0, depth = 0;
@@ -148,6 +164,7 @@ void refitTree(std::deque<Node*>& leafs) {
     marshal(g_scene, prims);
     if (!ok(crt_scene_update(g_ctx, prims.data(), (int)prims.size()), "refitTree/crt_scene_update")) return;
     if (!ok(crt_bvh_refit(g_ctx, CRT_REFIT_TIGHT), "refitTree/crt_bvh_refit")) return;
+    if (!okm(crt_mgpu_sync_scene(g_mgpu), "refitTree/crt_mgpu_sync_scene")) return;
     /* host boxes: bvh.cu:288-400, grow only */
     for (Node* leaf : leafs) {
         for (Node* p = leaf; p; p = p->parent) {
@@ -187,10 +204,10 @@ void startRayTracing(float width, float height, unsigned char*& pixelcolorBuffer
         ls[i].point = lights[i].point; ls[i].area = lights[i].area; ls[i].radius = lights[i].radius;
         ls[i].constantTerm = lights[i].constantTerm; ls[i].linearTerm = lights[i].linearTerm; ls[i].quadraticTerm = lights[i].quadraticTerm;
     }
-    if (!ok(crt_lights_set(g_ctx, ls.data(), (int)ls.size()), "startRayTracing/crt_lights_set")) return;
+    if (!okm(crt_mgpu_lights_set(g_mgpu, ls.data(), (int)ls.size()), "startRayTracing/crt_mgpu_lights_set")) return;
     crt_params p; crt_params_default(&p);
     p.width = (int)width; p.height = (int)height; p.bounces = numBounces;
     p.use_graph = 1;        /* the application's camera and frame size rarely change (main.cu:459,508): replay the launches */
     crt_camera cam; put(cam.position, cameraPosition); put(cam.target, cameraDirection);
-    ok(crt_render(g_ctx, &cam, &p, pixelcolorBuffer), "startRayTracing/crt_render");
+    okm(crt_mgpu_render(g_mgpu, &cam, &p, pixelcolorBuffer), "startRayTracing/crt_mgpu_render");
 }

@@ -213,6 +213,30 @@ int crt_tiles_unpack(crt_ctx*, const crt_params*, int src_rank, const void* dev_
 int crt_get_stats(crt_ctx*, crt_stats*);
 int crt_sync(crt_ctx*);
 
+/* ---- the same exchange done for you: one process, every GPU of the node (no counterpart in the
+ *      reference, which is single-GPU: startRayTracing in compat/ uses this layer when more than one GPU is visible).
+ *      One crt_ctx per device; rank 0's context owns the scene (crt_scene_set / crt_bvh_build / crt_bvh_refit /
+ *      crt_animate_device on crt_mgpu_ctx(m, 0)), crt_mgpu_sync_scene replicates it with ONE ncclBroadcast of the
+ *      packed blob, crt_mgpu_render renders every rank's tiles on its own host thread and gathers them to rank 0 with
+ *      one group of ncclSend / ncclRecv (R - 1 point-to-point transfers, each over its own xGMI link).  No reduction.
+ *      devices = NULL: all visible GPUs.  A list with repeats (e.g. {0,0,0}) makes logical ranks on one GPU for
+ *      rehearsal: RCCL refuses duplicate devices, so the two exchanges become device-to-device copies. ---- */
+typedef struct crt_mgpu crt_mgpu;
+#define CRT_MGPU_RCCL_ALWAYS 1   /* create the communicator even for a single GPU (default: one GPU never loads RCCL) */
+crt_mgpu* crt_mgpu_create(const int* devices, int ndev, int flags, int* err);
+void crt_mgpu_destroy(crt_mgpu*);
+int crt_mgpu_size(const crt_mgpu*);
+int crt_mgpu_uses_rccl(const crt_mgpu*);                       /* 1: RCCL communicator; 0: local device-to-device copies */
+crt_ctx* crt_mgpu_ctx(crt_mgpu*, int rank);
+const char* crt_mgpu_last_error(crt_mgpu*);
+int crt_mgpu_lights_set(crt_mgpu*, const crt_light* lights, int n);
+int crt_mgpu_sync_scene(crt_mgpu*);                            /* after every build / refit / animation step on rank 0 */
+int crt_mgpu_render(crt_mgpu*, const crt_camera*, const crt_params*, unsigned char* bgr_out_host);
+/* leaves the assembled frame on rank 0's device (its address in *dev_frame_rank0, valid until the next render) */
+int crt_mgpu_render_device(crt_mgpu*, const crt_camera*, const crt_params*, void** dev_frame_rank0);
+/* wall milliseconds of the last crt_mgpu_render_device: all ranks' render + pack, the gather, the unpack on rank 0 */
+int crt_mgpu_get_times(crt_mgpu*, double* ms_render, double* ms_exchange, double* ms_unpack);
+
 /* ---- host-side scene layer (replaces objloader.cpp:20-112, the scene literals of
  *      main.cu:230-321 and the animation step main.cu:545-573) ---- */
 int crt_load_obj(const char* path, float* verts3, float* norms3, int max_corners);   /* returns corner count */
