@@ -424,6 +424,29 @@ def main():
             out["config"]["frame_ms_with_d2h_copy"] = round((time.perf_counter() - t1) / 3 * 1e3, 4)
         if a.out_bmp and world == 1:
             crt.write_bmp(a.out_bmp, ctx.render(cam, tgt, params), fw, fh)
+        if world == 1 and a.bvh != 2:
+            # the same scene rebuilt ON THE DEVICE (lbvh.hip + refrank.hip: wide LBVH with the reference's
+            # tie-break ranks), after the timed region: its build time, and the frame time on that tree
+            c2 = crt.Context(local_rank)
+            try:
+                c2.set_scene(prims); c2.set_lights(lights)
+                c2.build(2)                               # first build allocates
+                bms = []
+                for _ in range(3):
+                    c2.build(2); bms.append(c2.stats()["ms_build_device"])
+                c2.render_device(cam, tgt, params)
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    c2.render_device(cam, tgt, params)
+                c2.sync()
+                fms = (time.perf_counter() - t1) / 3 * 1e3
+                out["config"]["bvh_build_device_ms"] = round(min(bms), 3)
+                out["config"]["device_built_tree"] = {"build_ms": round(min(bms), 3), "build_ms_runs": [round(b, 3) for b in bms],
+                                                      "frame_ms": round(fms, 4), "mrays_per_s": round(total_rays / fms / 1e3, 1),
+                                                      "nodes": c2.stats()["nodes"], "depth": c2.stats()["depth"],
+                                                      "tie_break": "reference leaf order, replayed on the device"}
+            finally:
+                c2.close()
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prims, lights, cam, tgt, fw, fh, a.bounces, a.cpu_threads)
         else:

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstring>
 #include <thread>
+#include <memory>
 #include <functional>
 #include <cstdlib>
 
@@ -61,45 +62,59 @@ inline void choose_axis(RefNode& n, const float mid[3]) {
     if (ez > ex && ez > ey) { n.longestAxis = 2; n.midpoint = mid[2]; }
 }
 
+/* Threads for the host builders: subtrees over disjoint primitive ranges are independent, so a node whose range is
+ * larger than `cutoff` hands its left child to a new thread and keeps the right one.  The results do not depend on the
+ * schedule: every node's own loop (the order-dependent float sums included) stays sequential, and the node numbering is
+ * the serial one.  CRT_BUILD_THREADS=1 builds on the calling thread alone. */
+int build_cutoff(int n) {
+    if (const char* e = getenv("CRT_BUILD_THREADS")) if (atoi(e) == 1) return n;
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw <= 1) return n;
+    return std::max(n / 64, 8192);
+}
+
+/* The descendants of one node in the reference's creation order (bvh.cu:12-273 appends both children, then recurses into
+ * the left and the right one): [left, right, descendants of left..., descendants of right...].  Links are LOCAL indices
+ * into `nodes`; parent == -1 marks the two children of the block's owner. */
+struct RefSub {
+    std::vector<RefNode> nodes;
+    int depth = 0;
+};
+
 struct RefBuilder {
     const crt_prim* prims;
     const std::vector<Centroid>& cen;
-    RefTree& t;
-    std::vector<int> scratch;
-    RefBuilder(const crt_prim* p, const std::vector<Centroid>& c, RefTree& tt) : prims(p), cen(c), t(tt) {}
+    std::vector<int>& order;
+    int cutoff;
+    RefBuilder(const crt_prim* p, const std::vector<Centroid>& c, std::vector<int>& o, int cut) : prims(p), cen(c), order(o), cutoff(cut) {}
 
-    /* objects of node `ni` are t.order[first, first+count) */
-    int split(int ni, int first, int count, int depth) {
-        if (depth > t.depth) t.depth = depth;
+    /* `node` (box, axis, midpoint set) covers order[first, first+count); its descendants go to `sub` */
+    int split(RefNode& node, int first, int count, int depth, RefSub& sub, std::vector<int>& scratch) {
+        if (depth > sub.depth) sub.depth = depth;
         if (count <= kMaxLeafPrims) {
-            RefNode& n = t.nodes[ni];
-            n.isleaf = true; n.first = first; n.count = count;
-            t.leafs.push_back(ni);
+            node.isleaf = true; node.first = first; node.count = count;
             return 0;
         }
         if (depth > 256) return CRT_ERR_BUILD;
-        int li = (int)t.nodes.size();
-        t.nodes.emplace_back(); t.nodes.emplace_back();
-        int ri = li + 1;
         RefNode zero; std::memset(&zero, 0, sizeof(zero));
-        zero.left = zero.right = -1; zero.parent = ni;
-        t.nodes[li] = zero; t.nodes[ri] = zero;
-        box_reset(t.nodes[li]); box_reset(t.nodes[ri]);
-        const int axis = (int)t.nodes[ni].longestAxis;
-        const float mid = t.nodes[ni].midpoint;
+        zero.left = zero.right = -1; zero.parent = -1;
+        RefNode L = zero, R = zero;
+        box_reset(L); box_reset(R);
+        const int axis = (int)node.longestAxis;
+        const float mid = node.midpoint;
         /* stable partition; centroid sums accumulate in object order (bvh.cu:85,130,151,196) */
         float sumL[3] = {0, 0, 0}, sumR[3] = {0, 0, 0};
         int nl = 0, nr = 0;
         if ((int)scratch.size() < count) scratch.resize(count);
-        int* ord = &t.order[first];
+        int* ord = &order[first];
         for (int i = 0; i < count; i++) {
             int o = ord[i];
             if (cen[o].c[axis] <= mid) {
-                grow(t.nodes[li], prims[o]);
+                grow(L, prims[o]);
                 for (int a = 0; a < 3; a++) sumL[a] += cen[o].c[a];
                 ord[nl++] = o;
             } else {
-                grow(t.nodes[ri], prims[o]);
+                grow(R, prims[o]);
                 for (int a = 0; a < 3; a++) sumR[a] += cen[o].c[a];
                 scratch[nr++] = o;
             }
@@ -107,12 +122,38 @@ struct RefBuilder {
         std::copy(scratch.begin(), scratch.begin() + nr, ord + nl);
         float midL[3], midR[3];
         for (int a = 0; a < 3; a++) { midL[a] = sumL[a] / (float)(size_t)nl; midR[a] = sumR[a] / (float)(size_t)nr; }
-        choose_axis(t.nodes[li], midL);
-        choose_axis(t.nodes[ri], midR);
-        t.nodes[ni].left = li; t.nodes[ni].right = ri;
-        int rc = split(li, first, nl, depth + 1);
-        if (rc) return rc;
-        return split(ri, first + nl, nr, depth + 1);
+        choose_axis(L, midL);
+        choose_axis(R, midR);
+        RefSub subL, subR;
+        int rcL = 0, rcR = 0;
+        if (count > cutoff) {
+            std::thread th([&] { std::vector<int> sc; rcL = split(L, first, nl, depth + 1, subL, sc); });
+            rcR = split(R, first + nl, nr, depth + 1, subR, scratch);
+            th.join();
+        } else {
+            rcL = split(L, first, nl, depth + 1, subL, scratch);
+            if (!rcL) rcR = split(R, first + nl, nr, depth + 1, subR, scratch);
+        }
+        if (rcL) return rcL;
+        if (rcR) return rcR;
+        /* this node's block: [L, R, block of L, block of R] */
+        const int base = (int)sub.nodes.size();
+        const int offL = base + 2, offR = offL + (int)subL.nodes.size();
+        if (!L.isleaf) { L.left += offL; L.right += offL; }
+        if (!R.isleaf) { R.left += offR; R.right += offR; }
+        sub.nodes.reserve(sub.nodes.size() + 2 + subL.nodes.size() + subR.nodes.size());
+        sub.nodes.push_back(L); sub.nodes.push_back(R);
+        auto append = [&](const RefSub& c, int off, int owner) {
+            for (RefNode nd : c.nodes) {
+                nd.parent = nd.parent < 0 ? owner : nd.parent + off;
+                if (!nd.isleaf) { nd.left += off; nd.right += off; }
+                sub.nodes.push_back(nd);
+            }
+        };
+        append(subL, offL, base); append(subR, offR, base + 1);
+        node.left = base; node.right = base + 1;        /* relative to this block; the caller shifts them */
+        sub.depth = std::max(sub.depth, std::max(subL.depth, subR.depth));
+        return 0;
     }
 };
 
@@ -153,10 +194,29 @@ int build_reference_tree(const crt_prim* prims, int n, RefTree& t) {
     for (int i = 0; i < n; i++) grow(root, prims[i]);
     float mid[3] = {(root.maxX + root.minX) / 2, (root.maxY + root.minY) / 2, (root.maxZ + root.minZ) / 2};
     choose_axis(root, mid);
+    RefBuilder b(prims, cen, t.order, build_cutoff(n));
+    RefSub sub;
+    std::vector<int> scratch;
+    const int rc = b.split(root, 0, n, 0, sub, scratch);
+    if (rc) { t.nodes.push_back(root); return rc; }
+    /* the root is node 0; its block follows */
+    t.nodes.reserve(sub.nodes.size() + 1);
+    if (!root.isleaf) { root.left += 1; root.right += 1; }
     t.nodes.push_back(root);
-    t.nodes.reserve(n / 16 + 64);
-    RefBuilder b(prims, cen, t);
-    return b.split(0, 0, n, 0);
+    for (RefNode nd : sub.nodes) {
+        nd.parent = nd.parent < 0 ? 0 : nd.parent + 1;
+        if (!nd.isleaf) { nd.left += 1; nd.right += 1; }
+        t.nodes.push_back(nd);
+    }
+    t.depth = sub.depth;
+    /* leaves in the order the reference's recursion reaches them (left before right) */
+    std::vector<int> stack{0};
+    while (!stack.empty()) {
+        const int ni = stack.back(); stack.pop_back();
+        if (t.nodes[ni].isleaf) { t.leafs.push_back(ni); continue; }
+        stack.push_back(t.nodes[ni].right); stack.push_back(t.nodes[ni].left);
+    }
+    return 0;
 }
 
 void refit_reference_tree(const crt_prim* prims, RefTree& t) {
@@ -269,19 +329,22 @@ WideTuning wide_tuning() {
     return t;
 }
 
+/* Binary SAH tree in a preallocated array: the node of a range of `count` primitives sits at index `ni`, its left
+ * subtree from ni + 1, its right subtree from ni + 2 * (primitives on the left) -- a subtree over c primitives has at
+ * most 2c - 1 nodes, so the blocks never overlap and subtrees can be built by different threads without any exchange.
+ * Unused entries are never read (the collapse follows links only). */
 struct WideBuilder {
     std::vector<PrimRef>& refs;
-    std::vector<BNode> nodes;
+    BNode* nodes;
     WideTuning tune;
-    explicit WideBuilder(std::vector<PrimRef>& r) : refs(r), tune(wide_tuning()) {}
+    int cutoff;
+    WideBuilder(std::vector<PrimRef>& r, BNode* storage, int cut) : refs(r), nodes(storage), tune(wide_tuning()), cutoff(cut) {}
 
-    int build(int first, int count) {
-        int ni = (int)nodes.size();
-        nodes.emplace_back();
+    void build(int first, int count, int ni) {
         AABB box, cb; box.reset(); cb.reset();
         for (int i = first; i < first + count; i++) { box.add(refs[i].box); cb.addp(refs[i].c); }
         nodes[ni].box = box; nodes[ni].left = nodes[ni].right = -1; nodes[ni].first = first; nodes[ni].count = count;
-        if (count <= 1) return ni;
+        if (count <= 1) return;
         int bestAxis = -1, bestSplit = -1; float bestCost = kFmax;
         for (int a = 0; a < 3; a++) {
             float ext = cb.hi[a] - cb.lo[a];
@@ -308,7 +371,7 @@ struct WideBuilder {
         if (count <= tune.max_leaf) {
             const float a = box.area();
             const float split_cost = (bestAxis >= 0 && a > 0.f) ? tune.node_cost + bestCost / a : kFmax;
-            if ((float)count <= split_cost) return ni;
+            if ((float)count <= split_cost) return;
         }
         int mid;
         if (bestAxis < 0) {
@@ -324,10 +387,16 @@ struct WideBuilder {
             mid = (int)(it - refs.begin());
             if (mid == first || mid == first + count) mid = first + count / 2;
         }
-        int l = build(first, mid - first);
-        int r = build(mid, first + count - mid);
+        const int l = ni + 1, r = ni + 2 * (mid - first);
+        if (count > cutoff) {
+            std::thread th([&] { build(first, mid - first, l); });
+            build(mid, first + count - mid, r);
+            th.join();
+        } else {
+            build(first, mid - first, l);
+            build(mid, first + count - mid, r);
+        }
         nodes[ni].left = l; nodes[ni].right = r;
-        return ni;
     }
 };
 
@@ -346,9 +415,9 @@ int build_wide(const crt_prim* prims, int n, const RefTree* ref, HostBVH& out) {
         for (int a = 0; a < 3; a++) refs[i].c[a] = 0.5f * (refs[i].box.lo[a] + refs[i].box.hi[a]);
         refs[i].idx = i;
     }
-    WideBuilder wb(refs);
-    wb.nodes.reserve((size_t)n);
-    if (n > 0) wb.build(0, n);
+    std::unique_ptr<BNode[]> storage(new BNode[(size_t)2 * (size_t)std::max(n, 1)]);      /* not initialised: see WideBuilder */
+    WideBuilder wb(refs, storage.get(), build_cutoff(n));
+    if (n > 0) wb.build(0, n, 0);
 
     Node8 rootn; node_clear(rootn);
     out.nodes8.push_back(rootn);

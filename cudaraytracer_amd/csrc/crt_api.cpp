@@ -85,6 +85,8 @@ struct crt_ctx {
     void* d_lbvh = nullptr; size_t lbvh_cap = 0;                 /* scratch of the device builder */
     Node8* d_lbvh_nodes = nullptr; size_t lbvh_nodes_cap = 0;    /* its output before the blob is laid out */
     uint32_t* d_lbvh_s2s = nullptr; size_t lbvh_s2s_cap = 0;
+    void* d_refrank = nullptr; size_t refrank_cap = 0;          /* scratch of the device-side reference-order pass */
+    uint32_t* d_refrank_out = nullptr; size_t refrank_out_cap = 0; bool dev_rank_valid = false; uint32_t refrank_levels = 0;
     uint32_t* d_status = nullptr;
     uint32_t* h_status = nullptr;      /* pinned: crt_trace_noalloc reads the status word without a staging copy */
     void* noalloc_scratch = nullptr;   /* this device's copy of noalloc.hip's scratch array (address looked up once per device) */
@@ -381,7 +383,7 @@ void crt_destroy(crt_ctx* c) {
                     c->coef[0], c->coef[1], c->pix[0], c->pix[1], c->hitSlot, c->hitT, c->rc, c->contrib, c->shO, c->shD,
                     c->accum, c->sum, c->shflag, c->d_bgr, c->cap_ids, c->cap_ts, c->d_tiles, c->d_ctr, c->d_status,
                     c->d_testctr, c->d_ovf, c->d_sortkeys, c->d_sortperm, c->d_sorthist, c->d_sortkeys2, c->d_sortperm2,
-                    c->d_lbvh, c->d_lbvh_nodes, c->d_lbvh_s2s, c->d_area_table};
+                    c->d_lbvh, c->d_lbvh_nodes, c->d_lbvh_s2s, c->d_area_table, c->d_refrank, c->d_refrank_out};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_status) hipHostFree(c->h_status);
@@ -508,6 +510,23 @@ static int build_on_device(crt_ctx* c) {
     std::string err;
     rc = lbvh_build(c->d_lbvh, c->d_prims, n, c->d_lbvh_nodes, n, c->d_lbvh_s2s, &nnodes, &depth, root_box, c->stream, &err);
     if (rc) return fail(c, rc, err.c_str());
+    /* tie-break ranks: the reference's own leaf order, replayed on the device (refrank.hip).  Where its recursion does not
+     * terminate (more than 64 primitives sharing a centroid coordinate on the split axis) ties resolve by scene index */
+    c->dev_rank_valid = false;
+    if (!getenv("CRT_DEVICE_BUILD_NO_REFRANK")) {
+        const size_t rneed = refrank_scratch_bytes(n);
+        if (rneed > c->refrank_cap || !c->d_refrank) {
+            if (c->d_refrank) HIPCHECK(c, hipFree(c->d_refrank));
+            c->d_refrank = nullptr;
+            HIPCHECK(c, hipMalloc(&c->d_refrank, rneed + rneed / 8));
+            c->refrank_cap = rneed + rneed / 8;
+        }
+        if ((rc = ensure(c, c->d_refrank_out, c->refrank_out_cap, (size_t)n))) return rc;
+        std::string rerr;
+        rc = refrank_build(c->d_refrank, c->d_prims, n, root_box, c->d_refrank_out, &c->refrank_levels, c->stream, &rerr);
+        if (rc == CRT_OK) c->dev_rank_valid = true;
+        else if (rc != CRT_ERR_BUILD) return fail(c, rc, rerr.c_str());
+    }
 
     BlobHeader h{};
     h.magic = kBlobMagic; h.version = kBlobVersion;
@@ -525,7 +544,7 @@ static int build_on_device(crt_ctx* c) {
     char* b = (char*)c->d_blob;
     HIPCHECK(c, hipMemcpyAsync(b, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
     HIPCHECK(c, hipMemcpyAsync(b + h.off_nodes, c->d_lbvh_nodes, (size_t)nnodes * sizeof(Node8), hipMemcpyDeviceToDevice, c->stream));
-    launch_lbvh_maps(c->d_lbvh_s2s, n, (uint32_t*)(b + h.off_sidx), (uint32_t*)(b + h.off_slot_of), (uint32_t*)(b + h.off_rank), c->stream);
+    launch_lbvh_maps(c->d_lbvh_s2s, c->dev_rank_valid ? c->d_refrank_out : nullptr, n, (uint32_t*)(b + h.off_sidx), (uint32_t*)(b + h.off_slot_of), (uint32_t*)(b + h.off_rank), c->stream);
     if (h.nmats) HIPCHECK(c, hipMemcpyAsync(b + h.off_mats, c->mats.data(), (size_t)h.nmats * sizeof(Material), hipMemcpyHostToDevice, c->stream));
     launch_pack_prims(c->d_prims, c->d_matid, (const uint32_t*)(b + h.off_slot_of), n, (Geom*)(b + h.off_geom), (Shade*)(b + h.off_shade), c->stream);
     launch_quantize((const Node8*)(b + h.off_nodes), h.nnodes, (QNode8*)(b + h.off_qnodes), c->d_status, c->stream);
@@ -567,7 +586,7 @@ int crt_bvh_build(crt_ctx* c, int mode) {
      * reference topology then cannot be built at all; the wide tree is built without it and exact-t ties
      * resolve by scene index, as they do for the device build */
     int rc = build_reference_tree(c->prims.data(), n, c->ref);
-    c->have_ref = rc == 0;
+    c->have_ref = rc == 0; c->dev_rank_valid = false;
     if (rc && mode == CRT_BVH_REFERENCE)
         return fail(c, rc, "BVH build: the reference's split does not terminate on this scene (more than 64 primitives share a centroid "
                            "coordinate on the split axis); use CRT_BVH_WIDE or CRT_BVH_WIDE_DEVICE");
@@ -663,8 +682,13 @@ int crt_bvh_free(crt_ctx* c) {
 
 int crt_bvh_reference_order(crt_ctx* c, int32_t* rank_out, int n) {
     if (!c || !rank_out) return CRT_ERR_ARG;
-    if (!c->have_ref) return fail(c, CRT_ERR_STATE, "crt_bvh_reference_order: no reference order (no host build yet, a device build, or a scene on which the reference's split does not terminate)");
     if ((size_t)n != c->prims.size()) return fail(c, CRT_ERR_ARG, "crt_bvh_reference_order: n differs from the scene size");
+    if (!c->have_ref && c->dev_rank_valid && c->built) {          /* CRT_BVH_WIDE_DEVICE: the ranks were computed on the device */
+        HIPCHECK(c, hipSetDevice(c->device));
+        HIPCHECK(c, hipMemcpy(rank_out, c->d_refrank_out, (size_t)n * 4, hipMemcpyDeviceToHost));
+        return CRT_OK;
+    }
+    if (!c->have_ref) return fail(c, CRT_ERR_STATE, "crt_bvh_reference_order: no reference order (no build yet, or a scene on which the reference's split does not terminate)");
     for (int i = 0; i < n; i++) rank_out[c->ref.order[i]] = i;
     return CRT_OK;
 }

@@ -148,7 +148,13 @@ void launch_sort_rays(const float4* rayO, const uint32_t* count, uint32_t cap, c
 size_t lbvh_scratch_bytes(uint32_t n);
 int lbvh_build(void* scratch, const crt_prim* d_prims, uint32_t n, Node8* nodes_out, uint32_t node_cap, uint32_t* slot_to_scene,
                uint32_t* h_nnodes, uint32_t* h_depth, float root_box[6], hipStream_t s, std::string* err);
-void launch_lbvh_maps(const uint32_t* slot_to_scene, uint32_t n, uint32_t* sidx, uint32_t* slot_of, uint32_t* rank, hipStream_t s);
+/* rank_of_scene: the reference's leaf-order rank of every primitive (refrank.hip), or null = ties resolve by scene index */
+void launch_lbvh_maps(const uint32_t* slot_to_scene, const uint32_t* rank_of_scene, uint32_t n, uint32_t* sidx, uint32_t* slot_of, uint32_t* rank, hipStream_t s);
+/* the reference's centroid-mean partition replayed on the device (refrank.hip): rank_of_scene[i] = position of primitive i in
+ * the reference tree's leaf order.  CRT_ERR_BUILD where the reference's recursion does not terminate. */
+size_t refrank_scratch_bytes(uint32_t n);
+int refrank_build(void* scratch, const crt_prim* d_prims, uint32_t n, const float root_box[6], uint32_t* d_rank_of_scene, uint32_t* h_levels,
+                  hipStream_t s, std::string* err);
 struct AnimParam { float m[16]; };          /* column-major rotation of main.cu:548 */
 void animation_matrix(float out16[16]);     /* scene.cpp */
 void launch_animate(crt_prim* d_prims, uint32_t n, const AnimParam& a, hipStream_t s);

@@ -73,11 +73,15 @@ Scratch carve(void* base, uint32_t n, size_t* total) {
 __device__ __forceinline__ int32_t f2ord(float f) { const int32_t i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
 __device__ __forceinline__ float ord2f(int32_t i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 
+constexpr int kBoundsPerThread = 4;
 __global__ __launch_bounds__(256) void k_lbvh_bounds(const crt_prim* prims, uint32_t n, float4* plo, float4* phi, int32_t* cbox) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    float lo[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, hi[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
-    if (i < n) {
+    __shared__ float s_red[4][6];
+    float cmin[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, cmax[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+    for (int r = 0; r < kBoundsPerThread; r++) {
+        const uint32_t i = (blockIdx.x * kBoundsPerThread + r) * blockDim.x + threadIdx.x;
+        if (i >= n) break;
         const crt_prim& o = prims[i];
+        float lo[3], hi[3];
         if (o.type == 0) {
             for (int a = 0; a < 3; a++) { lo[a] = o.position[a] - o.radius; hi[a] = o.position[a] + o.radius; }
         } else {
@@ -88,19 +92,26 @@ __global__ __launch_bounds__(256) void k_lbvh_bounds(const crt_prim* prims, uint
         }
         plo[i] = make_float4(lo[0], lo[1], lo[2], 0.f);
         phi[i] = make_float4(hi[0], hi[1], hi[2], 0.f);
+        for (int a = 0; a < 3; a++) {
+            const float c = 0.5f * (lo[a] + hi[a]);
+            cmin[a] = fminf(cmin[a], c); cmax[a] = fmaxf(cmax[a], c);
+        }
     }
-    /* bounds of the box centres: wave reduction, then one atomic per wave and component */
-    for (int a = 0; a < 3; a++) {
-        float c = 0.5f * (lo[a] + hi[a]);
-        float cmin = i < n ? c : 3.402823466e+38f, cmax = i < n ? c : -3.402823466e+38f;
+    /* bounds of the box centres: wave reduction, the block's four waves through LDS, then one atomic per block and component
+     * (atomics on one address serialise at ~10 ns each: one per wave cost 1 ms for 1M primitives) */
+    for (int a = 0; a < 3; a++)
         for (int off = 32; off > 0; off >>= 1) {
-            cmin = fminf(cmin, __shfl_xor(cmin, off));
-            cmax = fmaxf(cmax, __shfl_xor(cmax, off));
+            cmin[a] = fminf(cmin[a], __shfl_xor(cmin[a], off));
+            cmax[a] = fmaxf(cmax[a], __shfl_xor(cmax[a], off));
         }
-        if ((threadIdx.x & 63u) == 0u && cmin <= cmax) {
-            atomicMin(&cbox[a], f2ord(cmin));
-            atomicMax(&cbox[3 + a], f2ord(cmax));
-        }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0u) for (int a = 0; a < 3; a++) { s_red[wave][a] = cmin[a]; s_red[wave][3 + a] = cmax[a]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        const float mn = fminf(fminf(s_red[0][a], s_red[1][a]), fminf(s_red[2][a], s_red[3][a]));
+        const float mx = fmaxf(fmaxf(s_red[0][3 + a], s_red[1][3 + a]), fmaxf(s_red[2][3 + a], s_red[3][3 + a]));
+        if (mn <= mx) { atomicMin(&cbox[a], f2ord(mn)); atomicMax(&cbox[3 + a], f2ord(mx)); }
     }
 }
 
@@ -165,27 +176,49 @@ __global__ __launch_bounds__(256) void k_lbvh_tree(const uint32_t* k, int n, uin
     if (i == 0) parent[0] = kNone;
 }
 
-/* boxes bottom-up: the second child to arrive at a node (agent-scope counter) carries on */
+/* Agent-coherent accesses to the internal boxes while k_lbvh_fit runs: 64-bit relaxed atomics at agent scope compile to
+ * global loads / stores that go through to the level all XCDs share, so no cache write-back or invalidate is needed
+ * around them (a release/acquire fence pair per node -- an L2 write-back each -- made this kernel 3.7 ms for 1M leaves). */
+__device__ __forceinline__ void store_agent(float4* p, const float4& v) {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+    const unsigned long long a = (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32);
+    const unsigned long long b = (unsigned long long)__float_as_uint(v.z) | ((unsigned long long)__float_as_uint(v.w) << 32);
+    __hip_atomic_store(q, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4 load_agent(const float4* p) {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(const_cast<float4*>(p));
+    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float4(__uint_as_float((uint32_t)a), __uint_as_float((uint32_t)(a >> 32)), __uint_as_float((uint32_t)b), __uint_as_float((uint32_t)(b >> 32)));
+}
+
+/* boxes bottom-up, one thread per leaf.  A thread carries the box of the subtree it has finished; at the parent the
+ * first child to arrive (agent-scope counter) stops, the second reads its sibling's box, merges, stores the parent's
+ * box and carries on.  Order at every node: box stores (agent scope), s_waitcnt vmcnt(0) = the stores are acknowledged,
+ * then the counter; the reader's loads come after its counter operation returned. */
 __global__ __launch_bounds__(256) void k_lbvh_fit(const float4* plo, const float4* phi, const uint32_t* vals, int n, const uint32_t* left,
                                                    const uint32_t* right, const uint32_t* parent, uint32_t* flags, float4* ilo, float4* ihi) {
     const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (j >= n) return;
+    uint32_t me = (uint32_t)j | kLeafBit;
+    float4 mlo = plo[vals[j]], mhi = phi[vals[j]];
     uint32_t node = parent[n - 1 + j];
     for (int guard = 0; guard < 4096 && node != kNone; guard++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t prev = __hip_atomic_fetch_add(&flags[node], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prev == 0u) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" ::: "memory");
         const uint32_t cl = left[node], cr = right[node];
-        const float4 al = (cl & kLeafBit) ? plo[vals[cl & ~kLeafBit]] : ilo[cl];
-        const float4 ah = (cl & kLeafBit) ? phi[vals[cl & ~kLeafBit]] : ihi[cl];
-        const float4 bl = (cr & kLeafBit) ? plo[vals[cr & ~kLeafBit]] : ilo[cr];
-        const float4 bh = (cr & kLeafBit) ? phi[vals[cr & ~kLeafBit]] : ihi[cr];
-        ilo[node] = make_float4(fminf(al.x, bl.x), fminf(al.y, bl.y), fminf(al.z, bl.z), 0.f);
-        ihi[node] = make_float4(fmaxf(ah.x, bh.x), fmaxf(ah.y, bh.y), fmaxf(ah.z, bh.z), 0.f);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t sib = cl == me ? cr : cl;
+        float4 slo, shi;
+        if (sib & kLeafBit) { const uint32_t p = vals[sib & ~kLeafBit]; slo = plo[p]; shi = phi[p]; }
+        else { slo = load_agent(&ilo[sib]); shi = load_agent(&ihi[sib]); }
+        mlo = make_float4(fminf(mlo.x, slo.x), fminf(mlo.y, slo.y), fminf(mlo.z, slo.z), 0.f);
+        mhi = make_float4(fmaxf(mhi.x, shi.x), fmaxf(mhi.y, shi.y), fmaxf(mhi.z, shi.z), 0.f);
+        store_agent(&ilo[node], mlo);
+        store_agent(&ihi[node], mhi);
+        me = node;
         node = parent[node];
     }
 }
@@ -279,11 +312,13 @@ __global__ __launch_bounds__(128) void k_lbvh_collapse(const QItem* qin, const u
     }
 }
 
-__global__ __launch_bounds__(256) void k_lbvh_maps(const uint32_t* slot_to_scene, uint32_t n, uint32_t* sidx, uint32_t* slot_of, uint32_t* rank) {
+__global__ __launch_bounds__(256) void k_lbvh_maps(const uint32_t* slot_to_scene, const uint32_t* rank_of_scene, uint32_t n, uint32_t* sidx,
+                                                    uint32_t* slot_of, uint32_t* rank) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
     const uint32_t si = slot_to_scene[s];
-    sidx[s] = si; slot_of[si] = s; rank[s] = si;        /* ties resolve by scene index in this mode */
+    sidx[s] = si; slot_of[si] = s;
+    rank[s] = rank_of_scene ? rank_of_scene[si] : si;    /* the reference's leaf order (refrank.hip), else ties resolve by scene index */
 }
 
 /* n == 1: a root whose only child is the leaf */
@@ -317,8 +352,8 @@ size_t lbvh_scratch_bytes(uint32_t n) {
         if (e_ != hipSuccess) { if (err) *err = std::string(#call) + ": " + hipGetErrorString(e_); return CRT_ERR_HIP; } \
     } while (0)
 
-void launch_lbvh_maps(const uint32_t* slot_to_scene, uint32_t n, uint32_t* sidx, uint32_t* slot_of, uint32_t* rank, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(k_lbvh_maps, dim3((n + 255u) / 256u), dim3(256), 0, s, slot_to_scene, n, sidx, slot_of, rank);
+void launch_lbvh_maps(const uint32_t* slot_to_scene, const uint32_t* rank_of_scene, uint32_t n, uint32_t* sidx, uint32_t* slot_of, uint32_t* rank, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_lbvh_maps, dim3((n + 255u) / 256u), dim3(256), 0, s, slot_to_scene, rank_of_scene, n, sidx, slot_of, rank);
 }
 
 int lbvh_build(void* scratch, const crt_prim* d_prims, uint32_t n, Node8* nodes_out, uint32_t node_cap, uint32_t* slot_to_scene,
@@ -330,7 +365,7 @@ int lbvh_build(void* scratch, const crt_prim* d_prims, uint32_t n, Node8* nodes_
     const int32_t init[6] = {big, big, big, -big, -big, -big};
     LB(hipMemcpyAsync(S.cbox, init, sizeof init, hipMemcpyHostToDevice, s));
     LB(hipMemsetAsync(S.ctr, 0, CTR_WORDS * 4, s));
-    hipLaunchKernelGGL(k_lbvh_bounds, dim3(blocks), dim3(256), 0, s, d_prims, n, S.plo, S.phi, S.cbox);
+    hipLaunchKernelGGL(k_lbvh_bounds, dim3((n + 256u * kBoundsPerThread - 1u) / (256u * kBoundsPerThread)), dim3(256), 0, s, d_prims, n, S.plo, S.phi, S.cbox);
     if (n == 1) {
         hipLaunchKernelGGL(k_lbvh_single, dim3(1), dim3(1), 0, s, S.plo, S.phi, nodes_out, slot_to_scene);
         float4 lo, hi;

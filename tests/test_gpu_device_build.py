@@ -75,13 +75,10 @@ def test_device_built_tree_is_valid_and_traces_like_the_oracle(crt, scene):
         hit = ids_o >= 0
         assert hit.sum() > 500
         bad = ids_g != ids_o
-        if scene == "clustered":
-            # duplicated geometry: exact-t ties resolve by scene index here, by the reference's leaf order in the oracle (class G2)
-            assert np.array_equal(ts_g[hit], ts_o[hit])
-            assert np.all(prims["position"][ids_g[bad]] == prims["position"][ids_o[bad]]) and np.all(prims["radius"][ids_g[bad]] == prims["radius"][ids_o[bad]])
-        else:
-            assert bad.sum() == 0, f"{bad.sum()} nearest-hit id mismatches"
-            assert np.array_equal(ts_g[hit], ts_o[hit])
+        # "clustered" holds duplicated geometry: its exact-t ties resolve by the reference's leaf order, which the device
+        # build now replays (refrank.hip), so the ids agree there too
+        assert bad.sum() == 0, f"{bad.sum()} nearest-hit id mismatches"
+        assert np.array_equal(ts_g[hit], ts_o[hit])
     finally:
         ctx.close(); sc.close()
 
@@ -108,6 +105,52 @@ def test_device_rebuild_in_the_animation_loop(crt):
                 assert int((diff > 1).sum()) == 0, f"frame {frame}: {int((diff > 1).sum())} pixels beyond 1 LSB"
     finally:
         ctx.close(); sc.close()
+
+
+@pytest.mark.parametrize("scene", ["teapot", "spheres", "soup", "dup", "chain", "soup1m"])
+def test_device_build_replays_the_reference_leaf_order(crt, scene):
+    """the tie-break ranks computed on the device (refrank.hip) equal the host restatement of newBuild/constructTree
+    (bvh_build.cpp build_reference_tree, itself checked against the oracle's tree) for every primitive"""
+    prims = {"teapot": lambda: crt.scene_teapot(with_sphere=True), "spheres": lambda: crt.scene_spheres(4096, seed=5),
+             "soup": lambda: crt.scene_soup(30000, seed=3), "soup1m": lambda: crt.scene_soup(1000000, seed=1),
+             "dup": lambda: np.concatenate([crt.scene_soup(3000, seed=2)] * 3 + [crt.scene_spheres(500, seed=4)] * 2),
+             "chain": lambda: crt.scene_spheres(300, seed=1)}[scene]()
+    if scene == "chain":         # exponentially spaced: a reference tree ~240 levels deep, one primitive peeled per level
+        k = np.arange(len(prims))
+        prims["position"][:, 0] = (1.08 ** k).astype(np.float32); prims["position"][:, 1:] = 0
+        prims["radius"] = (0.01 * 1.08 ** k).astype(np.float32)
+    ctx = crt.Context(0)
+    try:
+        ctx.set_scene(prims)
+        ctx.build(0); host = ctx.reference_order().copy()
+        ctx.build(DEVICE); dev = ctx.reference_order()
+        assert np.array_equal(np.sort(dev), np.arange(len(prims)))
+        assert np.array_equal(dev, host), f"{int((dev != host).sum())} ranks differ, first at {int(np.argmax(dev != host))}"
+        print(f"{scene}: n={len(prims)} device build {ctx.stats()['ms_build_device']:.2f} ms, host build {ctx.stats()['ms_build_host']:.1f} ms")
+    finally:
+        ctx.close()
+
+
+def test_device_build_without_a_reference_order(crt):
+    """more than 64 coincident centroids: the reference's recursion never ends (bvh.cu:12-273), so there is no reference
+    order; the device build still succeeds, ties resolve by scene index, and asking for the order is a state error"""
+    prims = crt.scene_spheres(400, seed=1)
+    prims["position"][:100] = (10, 20, 30)
+    prims["radius"][:100] = np.linspace(1, 5, 100, dtype=np.float32)
+    ctx = crt.Context(0)
+    try:
+        ctx.set_scene(prims); ctx.build(DEVICE)
+        with pytest.raises(crt.CrtError):
+            ctx.reference_order()
+        rays = random_rays(50000, 4)
+        ids_g, ts_g = ctx.trace(rays)
+        sc = orc.Scene(prims)
+        ids_b, ts_b = sc.trace_brute(rays)
+        sc.close()
+        hit = ids_b >= 0
+        assert hit.sum() > 200 and np.array_equal(ids_g >= 0, hit) and np.array_equal(ts_g[hit], ts_b[hit])
+    finally:
+        ctx.close()
 
 
 @pytest.mark.parametrize("n", [0, 1, 2, 9])

@@ -86,12 +86,14 @@ def walk_oracle(d):
     return leaves
 
 
-@pytest.mark.parametrize("scene", ["teapot", "spheres", "soup", "small"])
+@pytest.mark.parametrize("scene", ["teapot", "spheres", "soup", "small", "soup_threaded"])
 def test_reference_topology_equals_oracle_tree(crt, scene):
     """A12: the product's index-based restatement of newBuild/constructTree gives the oracle's tree:
     same leaf membership in DFS order (=> same tie-break ranks) and bit-identical boxes."""
     prims = {"teapot": lambda: crt.scene_teapot(), "spheres": lambda: crt.scene_spheres(3000, seed=9),
-             "soup": lambda: crt.scene_soup(20000, seed=5), "small": lambda: crt.scene_spheres(40, seed=1)}[scene]()
+             "soup": lambda: crt.scene_soup(20000, seed=5), "small": lambda: crt.scene_spheres(40, seed=1),
+             # large enough for the builders to hand subtrees to other threads (ranges above max(n/64, 8192) primitives)
+             "soup_threaded": lambda: crt.scene_soup(120000, seed=6)}[scene]()
     sc = orc.Scene(prims)
     sc.build()
     d = sc.dump()
@@ -155,6 +157,19 @@ def check_wide_hierarchy(crt, prims):
                 stack.append((link, b, depth + 1))
     assert seen.all() and depth_seen == h["depth"]
     return h
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_threaded_host_build_equals_the_serial_one(crt, mode, monkeypatch):
+    """the host builders hand subtrees over disjoint ranges to other threads; node numbering, slots, ranks and boxes
+    are those of the build on one thread (CRT_BUILD_THREADS=1), byte for byte"""
+    prims = np.concatenate([crt.scene_soup(90000, seed=3), crt.scene_spheres(20000, seed=4)])
+    threaded = crt.host_bvh(prims, mode)
+    monkeypatch.setenv("CRT_BUILD_THREADS", "1")
+    serial = crt.host_bvh(prims, mode)
+    assert threaded["depth"] == serial["depth"]
+    for k in ("root", "boxes", "links", "parents", "slot_to_scene", "rank_of_scene"):
+        assert np.array_equal(threaded[k], serial[k]), k
 
 
 def test_wide_bvh_is_a_valid_hierarchy(crt):
