@@ -25,6 +25,10 @@
 namespace crt {
 
 #define CRT_DEV __device__ __forceinline__
+/* lane mask of a predicate.  HIP's __ballot takes an int, and the compiler then rebuilds the mask it already holds in
+ * SGPRs with v_cndmask_b32 + v_cmp_ne_u32 -- two half-rate VALU instructions per vote, ten per iteration of the traversal
+ * loops; the intrinsic on the i1 is one s_and_b64 with exec. */
+#define crt_ballot(P) __builtin_amdgcn_ballot_w64((bool)(P))
 
 static_assert(kFetchChunk >= 1 && (kFetchChunk & (kFetchChunk - 1)) == 0, "CRT_FETCH_CHUNK must be a power of two");
 constexpr uint32_t kRegionAlign = kFetchChunk > 64 ? (uint32_t)kFetchChunk : 64u;      /* region size granule: a multiple of the chunk and of a wave */
@@ -153,7 +157,7 @@ __global__ CRT_TRACE_BOUNDS void k_trace(TraceArgs A) {
          *      with ONE atomic when it runs dry (per-refill atomics on the single fetch counter
          *      serialise at ~10 ns each and were the limit of this kernel) ---- */
         if (!exhausted) {
-            const unsigned long long idle = __ballot(!active);
+            const unsigned long long idle = crt_ballot(!active);
             const int nidle = __popcll(idle);
             if (nidle >= kRefillMinIdle) {
                 if (cnext >= cend) {
@@ -227,14 +231,14 @@ __global__ CRT_TRACE_BOUNDS void k_trace(TraceArgs A) {
                 }
             }
         }
-        if (__ballot(active) == 0ull) { if (exhausted) break; else continue; }
+        if (crt_ballot(active) == 0ull) { if (exhausted) break; else continue; }
 
         /* ---- traverse until enough lanes idle to be worth a refill ---- */
         do {
             const bool want_prim = active && (lp < lend);
             const bool want_node = active && !want_prim;
-            const int n_node = __popcll(__ballot(want_node));
-            const int n_prim = __popcll(__ballot(want_prim));
+            const int n_node = __popcll(crt_ballot(want_node));
+            const int n_prim = __popcll(crt_ballot(want_prim));
             bool finish = false;
             if (n_node * CRT_VOTE_PRIM_WEIGHT >= n_prim * CRT_VOTE_NODE_WEIGHT) {
                 if (want_node) {
@@ -348,7 +352,7 @@ __global__ CRT_TRACE_BOUNDS void k_trace(TraceArgs A) {
                 }
                 active = false; lp = lend = 0;
             }
-        } while (exhausted ? (__ballot(active) != 0ull) : (__popcll(__ballot(active)) > 64 - kRefillMinIdle));
+        } while (exhausted ? (crt_ballot(active) != 0ull) : (__popcll(crt_ballot(active)) > 64 - kRefillMinIdle));
     }
 #undef POP_ITEM
 #undef PUSH_ITEM
@@ -491,9 +495,12 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
          *      loads return later (loads return in order), so the refill costs the wave no extra stall ---- */
         bool pend = false;
         float4 pro4, prd;      /* read only by the lanes that set pend; `ray` carries the queue index */
+        /* one vote on `active` serves the refill trigger, the "anything to do" test and the node count below: every
+         * vote on a bool costs two VALU instructions (the compiler rebuilds the lane mask through a VGPR) */
+        const unsigned long long amask = crt_ballot(active);
         if (!exhausted) {
-            const unsigned long long idle = __ballot(!active);
-            const int nidle = __popcll(idle);
+            const unsigned long long idle = ~amask;
+            const int nidle = 64 - __popcll(amask);
             if (nidle >= kRefillMinIdle8) {
                 if (COUNT && lane == 0) itc[1]++;
                 if (cnext >= cend) {
@@ -549,12 +556,12 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
         }
         CRT_MARK("refill1_end")
         if (COUNT && lane == 0) itc[0]++;
-        if (__ballot(active) != 0ull) {
+        if (amask != 0ull) {
             CRT_MARK("vote_begin")
             const bool want_prim = active && (lp < lend || plm >= (1u << 24));
             const bool want_node = active && !want_prim;
-            const int n_node = __popcll(__ballot(want_node));
-            const int n_prim = __popcll(__ballot(want_prim));
+            const int n_prim = __popcll(crt_ballot(want_prim));
+            const int n_node = __popcll(amask) - n_prim;
             bool finish = false;
             if (COUNT && lane == 0) {     /* scheduling statistics: [8] node iterations [9] lanes served [10] prim iterations [11] lanes served [12] active lanes */
                 if (n_node * CRT_VOTE8_PRIM_WEIGHT >= n_prim * CRT_VOTE8_NODE_WEIGHT) { sch[0]++; sch[1] += n_node; } else { sch[2]++; sch[3] += n_prim; }
@@ -564,7 +571,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
             if (n_node * CRT_VOTE8_PRIM_WEIGHT >= n_prim * CRT_VOTE8_NODE_WEIGHT) {
                 CRT_MARK("node_begin")
                 if (want_node) {
-                    if (COUNT) { const bool any_ = __ballot((gmask & 0xffu) == 0u) != 0ull; if (lane == 0 && any_) itc[4]++; }
+                    if (COUNT) { const bool any_ = crt_ballot((gmask & 0xffu) == 0u) != 0ull; if (lane == 0 && any_) itc[4]++; }
                     CRT_MARK("pop_begin")
                     if ((gmask & 0xffu) == 0u) {
                         if (sp == 0) finish = true;
@@ -647,7 +654,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
             } else {
                 CRT_MARK("prim_begin")
                 if (want_prim) {
-                    if (COUNT) { const bool any_ = __ballot(lp == lend) != 0ull; if (lane == 0 && any_) itc[5]++; }
+                    if (COUNT) { const bool any_ = crt_ballot(lp == lend) != 0ull; if (lane == 0 && any_) itc[5]++; }
                     CRT_MARK("decode_begin")
                     if (lp == lend) {
                         const uint32_t k = (uint32_t)__ffs((int)(plm >> 24)) - 1u;
@@ -664,7 +671,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                     const bool shray = (ray >> 31) != 0u;
                     if (is_sphere(g)) { CRT_MARK("sphere_begin") if (COUNT) nsph[shray]++; hit = sphere_test(g, o, d, t, tsm); CRT_MARK("sphere_end") }
                     else { if (COUNT) ntri[shray]++; hit = tri_test(g, o, d, tbest, t); }
-                    if (COUNT) { const bool any_ = __ballot(hit) != 0ull; if (lane == 0 && any_) itc[6]++; }
+                    if (COUNT) { const bool any_ = crt_ballot(hit) != 0ull; if (lane == 0 && any_) itc[6]++; }
                     CRT_MARK("hit_begin")
                     if (hit) {
                         if (!shray) {
@@ -707,7 +714,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                 CRT_MARK("prim_end")
             }
             CRT_MARK("finish_begin")
-            if (COUNT) { const bool any_ = __ballot(finish) != 0ull; if (lane == 0 && any_) itc[2]++; }
+            if (COUNT) { const bool any_ = crt_ballot(finish) != 0ull; if (lane == 0 && any_) itc[2]++; }
             if (finish) {
                 if (!(ray >> 31)) {
                     A.hitSlot[ray] = best;
@@ -733,7 +740,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
             CRT_MARK("finish_end")
         }
         CRT_MARK("refill2_begin")
-        if (COUNT) { const bool any_ = __ballot(pend) != 0ull; if (lane == 0 && any_) itc[3]++; }
+        if (COUNT) { const bool any_ = crt_ballot(pend) != 0ull; if (lane == 0 && any_) itc[3]++; }
         /* ---- refill, second half: ray set-up for the lanes whose loads were issued above ---- */
         if (pend) {
             const float4 ro = pro4, rd = prd;
@@ -769,7 +776,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
             }
         }
         CRT_MARK("refill2_end")
-        if (exhausted && __ballot(active) == 0ull) break;
+        if (exhausted && crt_ballot(active) == 0ull) break;
     }
     if (COUNT) {
         for (int m = 0; m < 2; m++) {          /* nearest-hit counters at [0..3], shadow counters at [16..19] */
@@ -932,11 +939,11 @@ __global__ __launch_bounds__(256) void k_sort_count(const float4* rayO, const ui
         keys[i] = key;
         /* neighbouring rays mostly share a cell: one atomic per distinct key of the wave, not one per lane
          * (same-address atomics serialise) */
-        unsigned long long todo = __ballot(1);
+        unsigned long long todo = crt_ballot(1);
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
             const uint32_t k = (uint32_t)__shfl((int)key, leader);
-            const unsigned long long same = __ballot(key == k);
+            const unsigned long long same = crt_ballot(key == k);
             if (lane_id() == leader) atomicAdd(&hist[k], (uint32_t)__popcll(same));
             todo &= ~same;
             if (key == k) break;
@@ -965,11 +972,11 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint32_t* keys, cons
     const uint32_t total = *count;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const uint32_t key = keys[i];
-        unsigned long long todo = __ballot(1);
+        unsigned long long todo = crt_ballot(1);
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
             const uint32_t k = (uint32_t)__shfl((int)key, leader);
-            const unsigned long long same = __ballot(key == k);
+            const unsigned long long same = crt_ballot(key == k);
             uint32_t base = 0;
             if (lane_id() == leader) base = atomicAdd(&cursor[k], (uint32_t)__popcll(same));
             base = (uint32_t)__shfl((int)base, leader);
@@ -993,7 +1000,7 @@ void launch_sort_rays(const float4* rayO, const uint32_t* count, uint32_t cap, c
  * wave-aggregated queue append: one atomic per wave
  * ------------------------------------------------------------------------------------------ */
 CRT_DEV uint32_t queue_slot(bool want, uint32_t* counter) {
-    const unsigned long long m = __ballot(want);
+    const unsigned long long m = crt_ballot(want);
     if (m == 0ull) return 0;
     const int lane = threadIdx.x & 63;
     const int leader = __ffsll((long long)m) - 1;
@@ -1189,9 +1196,9 @@ __global__ CRT_SHADE_BOUNDS void k_shade(FrameParams P, FrameBuffers B, SceneVie
                 if (LP.l[j].area || LP.l[j].point) want = true;
                 else want = !((double)dot(normalize(vec3(LP.l[j].direction)), N) > -0.00001);
             }
-            wave_sh += (uint32_t)__popcll(__ballot(want)) * (LP.l[j].area ? (uint32_t)LP.area_samples : 1u);
+            wave_sh += (uint32_t)__popcll(crt_ballot(want)) * (LP.l[j].area ? (uint32_t)LP.area_samples : 1u);
         }
-        const unsigned long long emit_mask = __ballot(emit);
+        const unsigned long long emit_mask = crt_ballot(emit);
         if (lane == 0) { s_cnt[0][wv] = wave_sh; s_cnt[1][wv] = (uint32_t)__popcll(emit_mask); }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -1258,7 +1265,7 @@ __global__ CRT_SHADE_BOUNDS void k_shade(FrameParams P, FrameBuffers B, SceneVie
                     B.contrib[plane] = make_float4(X.x, X.y, X.z, distance);
                     B.shflag[plane] = flag;
                 }
-                const unsigned long long wm = __ballot(want);
+                const unsigned long long wm = crt_ballot(want);
                 if (want) {
                     const uint32_t ks = sh_run + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull));
                     B.shO[ks] = make_float4(sorg.x, sorg.y, sorg.z, __uint_as_float((uint32_t)plane));

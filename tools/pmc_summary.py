@@ -21,9 +21,45 @@ def short(name):
     return name.split("(")[0]
 
 
+def isa_metadata(path):
+    """per-kernel register / LDS / scratch figures from the code-object metadata in the compiler's assembly (make kernels.s)"""
+    import re
+    import subprocess
+    meta, cur = {}, None
+    if not os.path.exists(path):
+        return meta
+
+    def close(c):
+        if c and "name" in c:
+            try:
+                dem = subprocess.check_output(["c++filt", c["name"]], text=True).strip()
+            except Exception:
+                dem = c["name"]
+            meta[short(dem)] = {k: v for k, v in c.items() if k != "name"}
+    fields = {".vgpr_count": "vgpr", ".sgpr_count": "sgpr", ".private_segment_fixed_size": "scratch", ".group_segment_fixed_size": "lds",
+              ".agpr_count": "agpr"}
+    for line in open(path):
+        if line.startswith("  - .agpr_count:"):
+            close(cur)
+            cur = {"agpr": int(line.split()[-1])}
+            continue
+        if cur is None:
+            continue
+        m = re.match(r"    (\.\w+):\s+(\S+)\s*$", line)        # kernel-level keys sit at four spaces; argument fields deeper
+        if not m:
+            continue
+        if m.group(1) == ".name":
+            cur["name"] = m.group(2)
+        elif m.group(1) in fields:
+            cur[fields[m.group(1)]] = int(m.group(2))
+    close(cur)
+    return meta
+
+
 def main():
     src, dst = sys.argv[1], sys.argv[2]
     out = {"source": src, "kernels": {}}
+    isa = isa_metadata(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cudaraytracer_amd", "csrc", "kernels.s"))
     for f in glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv")):
         for r in csv.DictReader(open(f)):
             out["kernels"][short(r["Name"])] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
@@ -61,6 +97,14 @@ def main():
                 e["wait_any_frac_of_wave_cycles"] = pm["SQ_WAIT_ANY"] * 4 / pm["SQ_WAVE_CYCLES"] if False else pm["SQ_WAIT_ANY"] / pm["SQ_WAVE_CYCLES"]
         if "SQ_THREAD_CYCLES_VALU" in pm and pm.get("SQ_ACTIVE_INST_VALU", 0) > 0:
             e["valu_lane_utilisation"] = pm["SQ_THREAD_CYCLES_VALU"] / (pm["SQ_ACTIVE_INST_VALU"] * 64)
+        if pm.get("GRBM_GUI_ACTIVE", 0) > 0 and e.get("avg_ms", 0) > 0:
+            e["clock_ghz"] = pm["GRBM_GUI_ACTIVE"] / 8 / (e["avg_ms"] * 1e6)          # the counter sums the 8 XCDs
+            if "SQ_WAVE_CYCLES" in pm:
+                # SQ_WAVE_CYCLES advances once per 4 clocks per resident wave (5120 waves x launch clocks / 4 reproduces it for
+                # the persistent k_trace8); 1024 SIMDs
+                e["achieved_waves_per_simd"] = 4 * pm["SQ_WAVE_CYCLES"] / (pm["GRBM_GUI_ACTIVE"] / 8 * 1024)
+        if k in isa:
+            e["isa"] = isa[k]
     for name in ("bench_kt.json",):
         p = os.path.join(src, name)
         if os.path.exists(p):
@@ -83,10 +127,19 @@ def main():
                                  "bench.py --steps 2 --warmup 0)"},
                       open(os.path.join(os.path.dirname(dst) or ".", "latest_traffic.json"), "w"), indent=1)
     with open(dst + ".md", "w") as f:
-        f.write(f"# rocprofv3 summary ({src})\n\n| kernel | calls | avg ms | % | VGPR | LDS | L2 hit | HBM read/launch (raw, x2) | HBM write/launch | VALU lane util |\n|---|---|---|---|---|---|---|---|---|---|\n")
+        f.write(f"# rocprofv3 summary ({src})\n\n"
+                "VGPR: `rocprofv3` reports `VGPR_Count` in units of two registers on gfx950 (96 -> 48, 128 -> 64); the column shows the "
+                "profiler's figure / the code object's `.vgpr_count` (+ bytes of scratch) from the compiler's assembly, which is what "
+                "DESIGN.md quotes and what sets the occupancy.  Waves/SIMD = 4 x SQ_WAVE_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024): "
+                "resident waves per SIMD averaged over the launch (separate PMC passes of the same command).\n\n"
+                "| kernel | calls | avg ms | % | VGPR prof / ISA (+scratch B) | LDS | waves/SIMD | clock GHz | L2 hit | HBM read/launch (raw, x2) | HBM write/launch | VALU lane util |\n|---|---|---|---|---|---|---|---|---|---|---|---|\n")
         for k, e in sorted(out["kernels"].items(), key=lambda kv: -kv[1].get("total_ms", 0)):
-            f.write("| {} | {} | {:.4f} | {:.2f} | {} | {} | {} | {} | {} | {} |\n".format(
-                k, e.get("calls", ""), e.get("avg_ms", 0), e.get("pct", 0), e.get("vgpr", ""), e.get("lds", ""),
+            f.write("| {} | {} | {:.4f} | {:.2f} | {} | {} | {} | {} | {} | {} | {} | {} |\n".format(
+                k, e.get("calls", ""), e.get("avg_ms", 0), e.get("pct", 0),
+                "{} / {}".format(e.get("vgpr", ""), "{} (+{})".format(e["isa"].get("vgpr"), e["isa"].get("scratch")) if "isa" in e else "?"),
+                e.get("lds", ""),
+                "{:.2f}".format(e["achieved_waves_per_simd"]) if "achieved_waves_per_simd" in e else "",
+                "{:.3f}".format(e["clock_ghz"]) if "clock_ghz" in e and e.get("avg_ms", 0) > 0.1 else "",
                 "{:.3f}".format(e["l2_hit_rate"]) if "l2_hit_rate" in e else "",
                 "{:.1f} MB, {:.1f} MB".format(e["hbm_read_bytes_per_launch_raw"] / 1e6, e["hbm_read_bytes_per_launch_x2_gfx950"] / 1e6) if "hbm_read_bytes_per_launch_raw" in e else "",
                 "{:.1f} MB".format(e["hbm_write_bytes_per_launch"] / 1e6) if "hbm_write_bytes_per_launch" in e else "",
