@@ -71,7 +71,10 @@ def valu_issue_model(cst):
              "node": node, "pop": cst["sched_pop_iterations"], "between_pop": node, "between_node": node,
              "prim": prim, "decode": cst["sched_decode_iterations"], "between_decode": prim, "sphere": sph, "between_sphere": prim,
              "hit": cst["sched_hit_iterations"], "between_hit": prim, "between_prim": prim,
-             "finish": cst["sched_finish_iterations"], "between_finish": it, "refill2": cst["sched_setup_iterations"], "between_refill2": it}
+             "finish": cst["sched_finish_iterations"], "between_finish": it, "refill2": cst["sched_setup_iterations"], "between_refill2": it,
+             # the tail instantiation of the loop (queue dry, work sharing): its iterations are in the node / primitive / finish
+             # counts above and are priced with the main loop's regions; the region itself is the second copy of the code
+             "tail": 0, "between_tail": 0}
     tot = np.zeros(2)
     mix["breakdown"] = {}
     for name in R:

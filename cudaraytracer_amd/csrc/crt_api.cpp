@@ -824,7 +824,8 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
     if (rc) return rc;
     c->h_ctr.assign((size_t)spp * kCtrStride, 0);
     HIPCHECK(c, hipMemsetAsync(c->d_ctr, 0, (size_t)spp * kCtrStride * 4, c->stream));
-    if (c->counting) HIPCHECK(c, hipMemsetAsync(c->d_testctr, 0, 32 * sizeof(unsigned long long), c->stream));
+    static const bool tail_probe = getenv("CRT_TAIL_PROBE") != nullptr;
+    if (c->counting || tail_probe) HIPCHECK(c, hipMemsetAsync(c->d_testctr, 0, 32 * sizeof(unsigned long long), c->stream));
     if (c->capture) {
         HIPCHECK(c, hipMemsetD32Async((hipDeviceptr_t)c->cap_ids, -9, (size_t)p->bounces * npix, c->stream));
         HIPCHECK(c, hipMemsetD32Async((hipDeviceptr_t)c->cap_ts, 0, (size_t)p->bounces * npix, c->stream));
@@ -983,6 +984,13 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
     float tot = 0;
     hipEventElapsedTime(&tot, c->evpool[c->evlog.front().second], c->evpool[c->evlog.back().second]);
     st.ms_total = tot;
+    if (tail_probe && !c->counting) {
+        unsigned long long t[32];
+        HIPCHECK(c, hipMemcpy(t, c->d_testctr, sizeof t, hipMemcpyDeviceToHost));
+        const int launches = st.launches_trace_nearest + st.launches_trace_shadow + st.launches_trace_mixed;
+        fprintf(stderr, "[crt tail] %d launches, %.3f ms of traversal: wave tails (queue dry -> wave done) longest %.0f, mean %.0f shader clocks (s_memtime; / ~2320 for us)\n",
+                launches, st.ms_trace, (double)t[30], launches ? (double)t[31] / ((double)c->grid_blocks * (kTraceBlock / 64) * launches) : 0.0);
+    }
     if (c->counting) {
         unsigned long long t[32];
         HIPCHECK(c, hipMemcpy(t, c->d_testctr, sizeof t, hipMemcpyDeviceToHost));
@@ -990,8 +998,10 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
         {
             const unsigned long long* q = t + 8;
             fprintf(stderr, "[crt sched] node iterations %llu (%.1f lanes served), prim iterations %llu (%.1f lanes served), active lanes per iteration %.1f, "
-                            "visits with no child hit %llu of %llu; shadow rays that found an occluder %llu, their node visits after it %llu\n",
-                    q[0], q[0] ? (double)q[1] / q[0] : 0., q[2], q[2] ? (double)q[3] / q[2] : 0., (q[0] + q[2]) ? (double)q[4] / (q[0] + q[2]) : 0., q[5], t[3] + t[19], q[7], q[6]);
+                            "visits with no child hit %llu of %llu; shadow rays that found an occluder %llu, their node visits after it %llu; "
+                            "tail iterations %llu; wave tails (queue dry -> wave done, s_memtime ticks): longest %llu, mean %.0f\n",
+                    q[0], q[0] ? (double)q[1] / q[0] : 0., q[2], q[2] ? (double)q[3] / q[2] : 0., (q[0] + q[2]) ? (double)q[4] / (q[0] + q[2]) : 0., q[5], t[3] + t[19], q[7], q[6],
+                    t[27], t[30], (double)t[31] / ((double)c->grid_blocks * (kTraceBlock / 64) * 4.0));
         }
         st.box_tests = t[0]; st.tri_tests = t[1]; st.sph_tests = t[2]; st.node_visits = t[3];
         st.box_tests_shadow = t[16]; st.tri_tests_shadow = t[17]; st.sph_tests_shadow = t[18]; st.node_visits_shadow = t[19];

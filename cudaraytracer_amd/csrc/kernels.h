@@ -42,9 +42,17 @@ constexpr int kStackDepth = CRT_STACK_DEPTH;        /* per-lane entries in LDS: 
 #define CRT_TRACE8_MIN_WAVES 5         /* __launch_bounds__(256, n): 96 VGPRs, 5 waves per SIMD; 5 x 30.7 KB of LDS per CU */
 #endif
 #ifndef CRT_STACK_DEPTH8
-#define CRT_STACK_DEPTH8 14
+#define CRT_STACK_DEPTH8 12         /* 24 KB; with the 2 KB octant table and 4.3 KB of work-sharing records a block stays at the 30,720 B that let 5 blocks share a CU */
 #endif
 constexpr int kRefillMinIdle8 = CRT_REFILL8_MIN_IDLE;
+#ifndef CRT_STEAL_MIN_IDLE
+#define CRT_STEAL_MIN_IDLE 16          /* k_trace8, queue dry: idle lanes of a wave that start a steal step */
+#endif
+#ifndef CRT_STEAL_EVERY
+#define CRT_STEAL_EVERY 4              /* ... at most every n-th iteration (power of two) */
+#endif
+constexpr int kStealMinIdle = CRT_STEAL_MIN_IDLE;
+constexpr int kStealEvery = CRT_STEAL_EVERY;
 constexpr int kStackDepth8 = CRT_STACK_DEPTH8;      /* k_trace8: 64-bit entries, at most one per tree level */
 /* k_trace8 vote: a node step runs when n_node * PRIM_WEIGHT >= n_prim * NODE_WEIGHT */
 #ifndef CRT_VOTE8_PRIM_WEIGHT
@@ -126,6 +134,8 @@ struct TraceArgs {
     uint32_t* ovf; int32_t ovf_depth;        /* per-thread stack overflow area in HBM: ovf_depth entries of 4 B (k_trace) or 8 B (k_trace8) */
     unsigned long long* counters;            /* [0]=box [1]=tri [2]=sph tests [3]=node visits, when counting */
     uint32_t* status;            /* device error word: bit0 = stack overflow beyond ovf, bit1 = node not quantisable */
+    int32_t steal_min_idle, steal_every;     /* k_trace8 tail (set by launch_trace): idle lanes that start a steal step; at most every n-th iteration */
+    int32_t tail_probe;                      /* CRT_TAIL_PROBE=1: waves report how long they ran after the queue was dry (counters[30], [31]) */
 };
 
 int trace_grid_blocks(int device);

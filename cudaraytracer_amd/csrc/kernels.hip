@@ -19,6 +19,9 @@
  *   k_convert    Ray.cu:724-731 on the device.
  *   k_refit_*    refitTree (bvh.cu:288-400) as leaf pass + bottom-up pass with arrival counters.
  */
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
 #include "kernels.h"
 #include "vec.h"
 
@@ -444,8 +447,14 @@ template <bool COUNT>
 __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
     __shared__ uint2 s_stack[kStackDepth8][kTraceBlock];
     __shared__ uint8_t s_perm[8][256];     /* s_perm[R][m]: bit k of m moved to bit k ^ R */
+    /* work sharing in the tail (see "steal" below), indexed by the thread that OWNS the ray */
+    __shared__ unsigned long long s_key[kTraceBlock];      /* minimum over the ray's lanes: ordered t << 32 | rank, or a shadow outcome code */
+    __shared__ uint32_t s_cnt[kTraceBlock];                /* lanes still working on the ray */
+    __shared__ uint32_t s_best[kTraceBlock];               /* slot that holds the minimum */
+    __shared__ uint8_t s_pair[kTraceBlock];                /* steal step: the wave's offering lanes, compacted */
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    const int wbase = tid & ~63;
     for (int i = tid; i < 2048; i += kTraceBlock) {
         const int R_ = i >> 8, m = i & 255;
         int y = 0;
@@ -481,15 +490,26 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
     uint32_t plm = 0, meta0 = 0, meta1 = 0;    /* leaf children hit at the last node: first leaf slot (< 2^24) | hit mask by child << 24 */
     uint32_t lp = 0, lend = 0;
     int sp = 0;
-    int found = 0;
+    /* bit 0: a shadow ray has found an occluder with t > 1e-9; bit 1: a directional shadow ray met a hit with t <= 1e-9 (lit,
+     * overrides); bits 8-13: the lane that owns the ray; bits 16-19: stack entries given away from the bottom; bit 24: the
+     * ray is shared with other lanes of the wave (result goes through s_key / s_cnt) */
+    uint32_t fstate = 0;
+    uint32_t tick = 0;
     uint32_t lkind = kShadowDirectional;   /* shadow lanes: float bits of the ray's light distance (kernels.h) */
     unsigned long long nbox[2] = {0, 0}, ntri[2] = {0, 0}, nsph[2] = {0, 0}, nvis[2] = {0, 0};      /* [0] nearest-hit rays, [1] shadow rays */
     unsigned long long sch[5] = {0, 0, 0, 0, 0}, nzero = 0, nstale = 0, nfound = 0, nzero_t = 0, nculled_t = 0;
     unsigned long long itc[8] = {0, 0, 0, 0, 0, 0, 0, 0};      /* wave-level iterations: all, with a refill fetch, with a finishing lane, with a ray set-up,
                                                                  * node steps with a stack pop, primitive steps with a leaf decode, with a hit */
 
-    for (;;) {
-        CRT_MARK("refill1_begin")
+    /* One iteration of the traversal loop, instantiated twice: TAIL = false is the loop that runs while the ray queue lasts
+     * (refill, vote, node / primitive step, write-out); TAIL = true runs once this wave has found the queue dry -- no refill,
+     * and the idle lanes share the work of the busy ones (the steal step).  Keeping the two apart keeps the sharing logic
+     * (shared write-out, empty stack entries, 20 lane shuffles) out of the loop where 97 % of the time goes: in one loop
+     * it cost 19 % of the frame.  Returns true when the loop should end. */
+#define CRT_MARK8(NAME) if constexpr (!TAIL) { CRT_MARK(NAME) }
+    auto iteration = [&](auto tail_tag) __attribute__((always_inline)) -> bool {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        CRT_MARK8("refill1_begin")
         /* ---- refill, first half: when enough lanes are idle, take rays off the queue and ISSUE their
          *      loads; the set-up runs after this iteration's traversal step, whose own node / primitive
          *      loads return later (loads return in order), so the refill costs the wave no extra stall ---- */
@@ -498,6 +518,56 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
         /* one vote on `active` serves the refill trigger, the "anything to do" test and the node count below: every
          * vote on a bool costs two VALU instructions (the compiler rebuilds the lane mask through a VGPR) */
         const unsigned long long amask = crt_ballot(active);
+        if constexpr (TAIL) {
+        if (COUNT && lane == 0) itc[7]++;
+        /* ---- steal: the queue is dry and this wave is draining.  A launch ends when its longest ray does (a chain of a few
+         *      hundred dependent node visits), while most lanes of most waves idle: an idle lane now takes the BOTTOM stack
+         *      entry (the largest untouched subtree) of a lane that is still descending, together with a copy of its ray, and
+         *      traverses it as its own; the lanes of a ray fold their results into the owner's LDS record -- minimum of
+         *      (t, rank) for nearest-hit rays, which is what one lane's strict '<' plus rank tie-break computes too, and
+         *      the strongest outcome for directional shadow rays -- and the last one to finish writes it out.  Point-light and
+         *      area-sample shadow rays keep their lane (their predicate needs the one nearest hit's own arithmetic). ---- */
+        if (amask != 0ull && ((++tick) & (uint32_t)(A.steal_every - 1)) == 0u && __popcll(amask) <= 64 - A.steal_min_idle) {
+            const uint32_t nst = (fstate >> 16) & 15u;
+            const bool offer = active && (!(ray >> 31) || lkind == kShadowDirectional) && nst < 12u && (int)nst < kStackDepth8 && sp > (int)nst;
+            const unsigned long long omask = crt_ballot(offer);
+            const int noffer = __popcll(omask);
+            if (noffer > 0) {
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                const int orank = __popcll(omask & lt), irank = __popcll(~amask & lt);
+                const int ntake = noffer < 64 - __popcll(amask) ? noffer : 64 - __popcll(amask);
+                if (offer) s_pair[wbase + orank] = (uint8_t)lane;
+                if (offer && orank < ntake && !(fstate & (1u << 24))) { s_cnt[tid] = 1u; s_key[tid] = ~0ull; }      /* an unshared victim owns its ray */
+                __builtin_amdgcn_wave_barrier();
+                const bool take = !active && irank < ntake;
+                const int v = take ? (int)s_pair[wbase + irank] : lane;
+                const float c_ox = __shfl(o.x, v), c_oy = __shfl(o.y, v), c_oz = __shfl(o.z, v);
+                const float c_dx = __shfl(d.x, v), c_dy = __shfl(d.y, v), c_dz = __shfl(d.z, v);
+                const float c_ix = __shfl(ix, v), c_iy = __shfl(iy, v), c_iz = __shfl(iz, v);
+                const float c_anx = __shfl(anx, v), c_afx = __shfl(afx, v), c_any = __shfl(any_, v), c_afy = __shfl(afy, v);
+                const float c_anz = __shfl(anz, v), c_afz = __shfl(afz, v), c_tb = __shfl(tbest, v);
+                const uint32_t c_R = __shfl(R, v), c_ray = __shfl(ray, v), c_lk = __shfl(lkind, v), c_fs = __shfl(fstate, v);
+                const int c_best = __shfl(best, v);
+                if (take) {
+                    o = vec3(c_ox, c_oy, c_oz); d = vec3(c_dx, c_dy, c_dz);
+                    ix = c_ix; iy = c_iy; iz = c_iz; anx = c_anx; afx = c_afx; any_ = c_any; afy = c_afy; anz = c_anz; afz = c_afz;
+                    tbest = c_tb; best = c_best; R = c_R; ray = c_ray; lkind = c_lk;
+                    const uint32_t vnst = (c_fs >> 16) & 15u;
+                    const uint2 e = s_stack[vnst][wbase + v];
+                    gbase = e.x; gmask = e.y;
+                    s_stack[vnst][wbase + v] = make_uint2(e.x, e.y & ~0xffu);       /* taken: the victim will pop an empty group */
+                    sp = 0; lp = lend = 0; plm = 0;
+                    const uint32_t own = (c_fs >> 8) & 63u;
+                    fstate = (c_fs & 1u) | (own << 8) | (1u << 24);
+                    atomicAdd(&s_cnt[wbase + own], 1u);
+                    active = true;
+                }
+                if (offer && orank < ntake) fstate = (fstate + (1u << 16)) | (1u << 24);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        }
+        if constexpr (!TAIL)
         if (!exhausted) {
             const unsigned long long idle = ~amask;
             const int nidle = 64 - __popcll(amask);
@@ -554,10 +624,10 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                 }
             }
         }
-        CRT_MARK("refill1_end")
+        CRT_MARK8("refill1_end")
         if (COUNT && lane == 0) itc[0]++;
         if (amask != 0ull) {
-            CRT_MARK("vote_begin")
+            CRT_MARK8("vote_begin")
             const bool want_prim = active && (lp < lend || plm >= (1u << 24));
             const bool want_node = active && !want_prim;
             const int n_prim = __popcll(crt_ballot(want_prim));
@@ -567,12 +637,12 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                 if (n_node * CRT_VOTE8_PRIM_WEIGHT >= n_prim * CRT_VOTE8_NODE_WEIGHT) { sch[0]++; sch[1] += n_node; } else { sch[2]++; sch[3] += n_prim; }
                 sch[4] += n_node + n_prim;
             }
-            CRT_MARK("vote_end")
+            CRT_MARK8("vote_end")
             if (n_node * CRT_VOTE8_PRIM_WEIGHT >= n_prim * CRT_VOTE8_NODE_WEIGHT) {
-                CRT_MARK("node_begin")
+                CRT_MARK8("node_begin")
                 if (want_node) {
                     if (COUNT) { const bool any_ = crt_ballot((gmask & 0xffu) == 0u) != 0ull; if (lane == 0 && any_) itc[4]++; }
-                    CRT_MARK("pop_begin")
+                    CRT_MARK8("pop_begin")
                     if ((gmask & 0xffu) == 0u) {
                         if (sp == 0) finish = true;
                         else {
@@ -584,8 +654,8 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                             gbase = e.x; gmask = e.y;
                         }
                     }
-                    CRT_MARK("pop_end")
-                    if (!finish) {
+                    CRT_MARK8("pop_end")
+                    if (!finish && (!TAIL || (gmask & 0xffu) != 0u)) {          /* tail: a popped entry is empty when its group was given to another lane */
                         const uint32_t pbit = 31u - (uint32_t)__clz((int)(gmask & 0xffu));
                         const uint32_t slot = pbit ^ R;
                         gmask ^= 1u << pbit;
@@ -641,7 +711,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
 #undef PAIR23
                         const uint32_t vmask = h1.x >> 24, imask = em >> 24;
                         raw &= vmask;                       /* an empty slot can pass the padded test of a degenerate node */
-                        if (COUNT) { nbox[ray >> 31] += (unsigned long long)__popc(vmask); nvis[ray >> 31]++; if (raw == 0u) nzero++; if ((ray >> 31) && found) nstale++;
+                        if (COUNT) { nbox[ray >> 31] += (unsigned long long)__popc(vmask); nvis[ray >> 31]++; if (raw == 0u) nzero++; if ((ray >> 31) && (fstate & 1u)) nstale++;
                                      if (raw == 0u && (raw_far & vmask) != 0u) nzero_t++; nculled_t += (unsigned long long)__popc(raw_far & vmask & ~raw); }
                         gbase = h1.x & 0xffffffu;
                         gmask = (imask << 8) | (uint32_t)s_perm[R][raw & imask];
@@ -650,12 +720,12 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                         if (raw == 0u && sp == 0) finish = true;
                     }
                 }
-                CRT_MARK("node_end")
+                CRT_MARK8("node_end")
             } else {
-                CRT_MARK("prim_begin")
+                CRT_MARK8("prim_begin")
                 if (want_prim) {
                     if (COUNT) { const bool any_ = crt_ballot(lp == lend) != 0ull; if (lane == 0 && any_) itc[5]++; }
-                    CRT_MARK("decode_begin")
+                    CRT_MARK8("decode_begin")
                     if (lp == lend) {
                         const uint32_t k = (uint32_t)__ffs((int)(plm >> 24)) - 1u;
                         plm &= ~(1u << (24u + k));
@@ -663,16 +733,16 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                         lp = (plm & 0xffffffu) + (m & 31u);
                         lend = lp + ((m >> 5) & 3u) + 1u;
                     }
-                    CRT_MARK("decode_end")
+                    CRT_MARK8("decode_end")
                     const uint32_t p = lp++;
                     const GeomRec g = load_geom(A.sv.geom, p);
                     float t = 0.f, tsm;
                     bool hit;
                     const bool shray = (ray >> 31) != 0u;
-                    if (is_sphere(g)) { CRT_MARK("sphere_begin") if (COUNT) nsph[shray]++; hit = sphere_test(g, o, d, t, tsm); CRT_MARK("sphere_end") }
+                    if (is_sphere(g)) { CRT_MARK8("sphere_begin") if (COUNT) nsph[shray]++; hit = sphere_test(g, o, d, t, tsm); CRT_MARK8("sphere_end") }
                     else { if (COUNT) ntri[shray]++; hit = tri_test(g, o, d, tbest, t); }
                     if (COUNT) { const bool any_ = crt_ballot(hit) != 0ull; if (lane == 0 && any_) itc[6]++; }
-                    CRT_MARK("hit_begin")
+                    CRT_MARK8("hit_begin")
                     if (hit) {
                         if (!shray) {
                             if (t < tbest || (t == tbest && best >= 0 && A.sv.rank[p] < A.sv.rank[best])) { tbest = t; best = (int)p; }
@@ -683,8 +753,8 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                                  * t0 > 1e-9, Ray.cu:589).  Any hit t >= t0 that lies before the light by a margin far
                                  * above the rounding of that expression decides the same without knowing t0 */
                                 const bool area = (lkind >> 31) != 0u;
-                                if (found) {                  /* area sample known to be occluded: only a hit at t <= 1e-9 lights it */
-                                    if (!(t > 0.000000001f)) { found = 0; best = -1; finish = true; }
+                                if (fstate & 1u) {            /* area sample known to be occluded: only a hit at t <= 1e-9 lights it */
+                                    if (!(t > 0.000000001f)) { fstate &= ~1u; best = -1; finish = true; }
                                 } else {
                                     if (t < tbest) { tbest = t; best = (int)p; }
                                     if (area && !(t > 0.000000001f)) { best = -1; finish = true; }     /* t0 <= 1e-9: lit */
@@ -696,32 +766,64 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                                         const float slack = 2e-6f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z)) + 2e-4f;
                                         if (sqrtf(gx * gx + gy * gy + gz * gz) * 1.00001f + slack < __uint_as_float(lkind & 0x7fffffffu)) {
                                             if (COUNT) nfound++;
-                                            found = 1;
+                                            fstate |= 1u;
                                             if (area) { if (tbest > 0.000000001f) tbest = 0.000000001f; }
                                             else finish = true;
                                         }
                                     }
                                 }
                             } else {
-                                if (!(t > 0.000000001f)) { found = 0; finish = true; }
-                                else { if (COUNT && !found) nfound++; found = 1; if (tbest > 0.000000001f) tbest = 0.000000001f; }
+                                if (!(t > 0.000000001f)) { fstate = (fstate & ~1u) | 2u; finish = true; }
+                                else { if (COUNT && !(fstate & 1u)) nfound++; fstate |= 1u; if (tbest > 0.000000001f) tbest = 0.000000001f; }
                             }
                         }
                     }
-                    CRT_MARK("hit_end")
+                    CRT_MARK8("hit_end")
                     if (lp == lend && plm < (1u << 24) && (gmask & 0xffu) == 0u && sp == 0) finish = true;
                 }
-                CRT_MARK("prim_end")
+                CRT_MARK8("prim_end")
             }
-            CRT_MARK("finish_begin")
+            CRT_MARK8("finish_begin")
             if (COUNT) { const bool any_ = crt_ballot(finish) != 0ull; if (lane == 0 && any_) itc[2]++; }
             if (finish) {
+                if (TAIL && (fstate & (1u << 24))) {
+                    /* the ray is shared: fold this lane's part into the owner's record; the last lane to finish writes the result */
+                    const uint32_t oi = (uint32_t)wbase + ((fstate >> 8) & 63u);
+                    const bool shray = (ray >> 31) != 0u;
+                    unsigned long long key;
+                    if (!shray) {
+                        key = ~0ull;
+                        if (best >= 0) {
+                            uint32_t tb = __float_as_uint(tbest);
+                            tb ^= (tb >> 31) ? 0xffffffffu : 0x80000000u;          /* unsigned order = float order */
+                            key = ((unsigned long long)tb << 32) | (unsigned long long)A.sv.rank[best];
+                        }
+                    } else {
+                        key = (fstate & 2u) ? 0ull : ((fstate & 1u) ? 1ull : 2ull);      /* directional: lit-override < occluder < nothing */
+                    }
+                    atomicMin(&s_key[oi], key);
+                    __builtin_amdgcn_wave_barrier();
+                    if (!shray && best >= 0 && s_key[oi] == key) s_best[oi] = (uint32_t)best;
+                    __builtin_amdgcn_wave_barrier();
+                    if (atomicSub(&s_cnt[oi], 1u) == 1u) {
+                        const unsigned long long kmin = s_key[oi];
+                        if (!shray) {
+                            if (kmin == ~0ull) { A.hitSlot[ray] = -1; A.hitT[ray] = 1000000000.0f; }
+                            else {
+                                uint32_t tb = (uint32_t)(kmin >> 32);
+                                tb ^= (tb >> 31) ? 0x80000000u : 0xffffffffu;
+                                A.hitSlot[ray] = (int32_t)s_best[oi];
+                                A.hitT[ray] = __uint_as_float(tb);
+                            }
+                        } else if (kmin == 1ull) A.shflag[ray & 0x7fffffffu] = 1;
+                    }
+                } else
                 if (!(ray >> 31)) {
                     A.hitSlot[ray] = best;
                     A.hitT[ray] = tbest;
                 } else {
                     bool shadowed;
-                    if (lkind != kShadowDirectional && !found) {
+                    if (lkind != kShadowDirectional && !(fstate & 1u)) {
                         shadowed = false;
                         if (best >= 0) {
                             /* Ray.cu:625-629; k_shade computed dtoLight from this very origin */
@@ -732,16 +834,17 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                             shadowed = dtoLight > dtoLightIntersection;
                             if ((lkind >> 31) && !(tbest > 0.000000001f)) shadowed = false;   /* area samples: Ray.cu:589 */
                         }
-                    } else shadowed = (found != 0);
+                    } else shadowed = ((fstate & 1u) != 0);
                     if (shadowed) A.shflag[ray & 0x7fffffffu] = 1;
                 }
                 active = false; lp = lend = 0; plm = 0;
             }
-            CRT_MARK("finish_end")
+            CRT_MARK8("finish_end")
         }
-        CRT_MARK("refill2_begin")
+        CRT_MARK8("refill2_begin")
         if (COUNT) { const bool any_ = crt_ballot(pend) != 0ull; if (lane == 0 && any_) itc[3]++; }
         /* ---- refill, second half: ray set-up for the lanes whose loads were issued above ---- */
+        if constexpr (!TAIL)
         if (pend) {
             const float4 ro = pro4, rd = prd;
             const bool shray = (ray >> 31) != 0u;
@@ -770,14 +873,28 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                 any_ = (ngy ? o.y - py : o.y + py) * iy; afy = (ngy ? o.y + py : o.y - py) * iy;
                 anz = (ngz ? o.z - pz : o.z + pz) * iz; afz = (ngz ? o.z + pz : o.z - pz) * iz;
                 R = (ngx ? 0u : 4u) | (ngy ? 0u : 2u) | (ngz ? 0u : 1u);
-                tbest = 1000000000.0f; best = -1; sp = 0; found = 0; lp = lend = 0; plm = 0;
+                tbest = 1000000000.0f; best = -1; sp = 0; fstate = (uint32_t)lane << 8; lp = lend = 0; plm = 0;
                 gbase = 0; gmask = (1u << 8) | (1u << R);      /* a group whose only child is the root */
                 active = true;
             }
         }
-        CRT_MARK("refill2_end")
-        if (exhausted && crt_ballot(active) == 0ull) break;
+        CRT_MARK8("refill2_end")
+        if constexpr (TAIL) return crt_ballot(active) == 0ull;
+        else return exhausted;
+    };
+    while (!iteration(std::false_type{})) {}
+    unsigned long long t_dry = 0;
+    if (A.tail_probe) t_dry = __builtin_readcyclecounter();      /* s_memtime; CRT_TAIL_PROBE=1 only */
+    CRT_MARK("tail_begin")
+    if (crt_ballot(active) != 0ull)
+        while (!iteration(std::true_type{})) {}
+    CRT_MARK("tail_end")
+    if (A.tail_probe && lane == 0) {   /* [30] the longest, [31] the sum of the waves' tails (queue dry -> wave done), in s_memtime ticks */
+        const unsigned long long dt = __builtin_readcyclecounter() - t_dry;
+        atomicMax(&A.counters[30], dt);
+        atomicAdd(&A.counters[31], dt);
     }
+#undef CRT_MARK8
     if (COUNT) {
         for (int m = 0; m < 2; m++) {          /* nearest-hit counters at [0..3], shadow counters at [16..19] */
             atomicAdd(&A.counters[16 * m + 0], nbox[m]);
@@ -807,8 +924,15 @@ int trace_grid_blocks(int device) {
     return p.multiProcessorCount * per_cu;
 }
 
-void launch_trace(const TraceArgs& a, int mode, bool counting, bool wide, int blocks, hipStream_t s) {
+void launch_trace(const TraceArgs& a_in, int mode, bool counting, bool wide, int blocks, hipStream_t s) {
     dim3 g(blocks), b(kTraceBlock);
+    TraceArgs a = a_in;
+    /* tail work sharing of k_trace8; CRT_STEAL="min_idle,every" overrides the built-in setting (tuning experiments) */
+    static const int steal[2] = {[] { int i = kStealMinIdle, e = kStealEvery; if (const char* v = getenv("CRT_STEAL")) sscanf(v, "%d,%d", &i, &e); return i < 1 ? 1 : (i > 64 ? 65 : i); }(),
+                                 [] { int i = kStealMinIdle, e = kStealEvery; if (const char* v = getenv("CRT_STEAL")) sscanf(v, "%d,%d", &i, &e); int p2 = 1; while (p2 < e && p2 < 64) p2 <<= 1; return p2; }()};
+    a.steal_min_idle = steal[0]; a.steal_every = steal[1];
+    static const int probe = getenv("CRT_TAIL_PROBE") ? 1 : 0;
+    a.tail_probe = probe;
     if (wide) {          /* k_trace8 serves both of its queues in one launch; `mode` is not used */
         if (counting) hipLaunchKernelGGL((k_trace8<true>), g, b, 0, s, a);
         else hipLaunchKernelGGL((k_trace8<false>), g, b, 0, s, a);
