@@ -999,9 +999,9 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
             const unsigned long long* q = t + 8;
             fprintf(stderr, "[crt sched] node iterations %llu (%.1f lanes served), prim iterations %llu (%.1f lanes served), active lanes per iteration %.1f, "
                             "visits with no child hit %llu of %llu; shadow rays that found an occluder %llu, their node visits after it %llu; "
-                            "tail iterations %llu; wave tails (queue dry -> wave done, s_memtime ticks): longest %llu, mean %.0f\n",
+                            "tail iterations %llu; steal steps %llu, stack entries handed over %.0f\n",
                     q[0], q[0] ? (double)q[1] / q[0] : 0., q[2], q[2] ? (double)q[3] / q[2] : 0., (q[0] + q[2]) ? (double)q[4] / (q[0] + q[2]) : 0., q[5], t[3] + t[19], q[7], q[6],
-                    t[27], t[30], (double)t[31] / ((double)c->grid_blocks * (kTraceBlock / 64) * 4.0));
+                    t[27], t[30], (double)t[31]);
         }
         st.box_tests = t[0]; st.tri_tests = t[1]; st.sph_tests = t[2]; st.node_visits = t[3];
         st.box_tests_shadow = t[16]; st.tri_tests_shadow = t[17]; st.sph_tests_shadow = t[18]; st.node_visits_shadow = t[19];

@@ -564,6 +564,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                 }
                 if (offer && orank < ntake) fstate = (fstate + (1u << 16)) | (1u << 24);
                 __builtin_amdgcn_wave_barrier();
+                if (COUNT && !A.tail_probe && lane == 0) { atomicAdd(&A.counters[30], 1ull); atomicAdd(&A.counters[31], (unsigned long long)ntake); }
             }
         }
         }
