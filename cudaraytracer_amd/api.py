@@ -74,7 +74,7 @@ ABI_SYMBOLS = [
     "crt_scene_set", "crt_scene_update", "crt_lights_set", "crt_animate_device", "crt_scene_get",
     "crt_bvh_build", "crt_bvh_refit", "crt_bvh_free", "crt_bvh_reference_order", "crt_bvh_dump",
     "crt_render", "crt_render_device", "crt_set_capture", "crt_get_capture", "crt_get_color",
-    "crt_trace", "crt_trace_shadow", "crt_trace_noalloc",
+    "crt_trace", "crt_trace_shadow", "crt_trace_noalloc", "crt_powf_probe",
     "crt_blob_size", "crt_blob_device_ptr", "crt_blob_import_device",
     "crt_tile_owner", "crt_tiles_owned", "crt_tiles_pack", "crt_tiles_unpack",
     "crt_get_stats", "crt_sync",
@@ -104,7 +104,7 @@ for _name, _args in {
     "crt_render": [_vp, C.POINTER(Camera), C.POINTER(Params), _vp],
     "crt_render_device": [_vp, C.POINTER(Camera), C.POINTER(Params), _vp],
     "crt_get_capture": [_vp, _i, _vp, _vp, _i], "crt_get_color": [_vp, _vp, _i],
-    "crt_trace": [_vp, _vp, _i, _vp, _vp], "crt_trace_shadow": [_vp, _vp, _i, _vp],
+    "crt_trace": [_vp, _vp, _i, _vp, _vp], "crt_trace_shadow": [_vp, _vp, _i, _vp], "crt_powf_probe": [_vp, _vp, _vp, _i, _vp],
     "crt_trace_noalloc": [_vp, _vp, _i, _vp, _vp],
     "crt_blob_size": [_vp, C.POINTER(C.c_size_t)], "crt_blob_device_ptr": [_vp, C.POINTER(_vp)],
     "crt_blob_import_device": [_vp, _vp, C.c_size_t],
@@ -400,6 +400,14 @@ class Context:
         rays6 = np.ascontiguousarray(rays6, np.float32).reshape(-1, 6)
         out = np.zeros(len(rays6), np.uint8)
         self._ck(lib.crt_trace_shadow(self.h, _ptr(rays6), len(rays6), _ptr(out)))
+        return out
+
+    def powf_probe(self, x, y):
+        """pow(x, y) as k_shade's specular term evaluates it on the device (parity hook)"""
+        x = np.ascontiguousarray(x, np.float32); y = np.ascontiguousarray(y, np.float32)
+        assert x.shape == y.shape
+        out = np.zeros(x.shape, np.float32)
+        self._ck(lib.crt_powf_probe(self.h, _ptr(x), _ptr(y), x.size, _ptr(out)))
         return out
 
     def blob(self):

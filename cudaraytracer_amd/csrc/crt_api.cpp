@@ -1144,6 +1144,27 @@ done:
     return check_status(c);
 }
 
+int crt_powf_probe(crt_ctx* c, const float* x, const float* y, int n, float* out) {
+    if (!c || n < 0 || (n > 0 && (!x || !y || !out))) return fail(c, CRT_ERR_ARG, "crt_powf_probe: null argument");
+    if (n == 0) return CRT_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    const size_t bytes = (size_t)n * sizeof(float);
+    int rc = CRT_OK;
+    if (hipMalloc(&dx, bytes) != hipSuccess || hipMalloc(&dy, bytes) != hipSuccess || hipMalloc(&dout, bytes) != hipSuccess) rc = fail(c, CRT_ERR_HIP, "crt_powf_probe: hipMalloc failed");
+    if (rc == CRT_OK && (hipMemcpyAsync(dx, x, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                         hipMemcpyAsync(dy, y, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess)) rc = fail(c, CRT_ERR_HIP, "crt_powf_probe: copy failed");
+    if (rc == CRT_OK) {
+        launch_powf_probe(dx, dy, (uint32_t)n, dout, c->stream);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, CRT_ERR_HIP, "crt_powf_probe: launch or copy failed");
+    }
+    if (dx) hipFree(dx);
+    if (dy) hipFree(dy);
+    if (dout) hipFree(dout);
+    return rc;
+}
+
 int crt_trace(crt_ctx* c, const float* org_dir, int n, int32_t* prim_out, float* t_out) {
     if (!prim_out || !t_out) return fail(c, CRT_ERR_ARG, "crt_trace: null outputs");
     return trace_hook(c, org_dir, n, prim_out, t_out, nullptr);

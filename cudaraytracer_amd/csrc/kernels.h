@@ -175,6 +175,7 @@ void launch_refit(Node4* nodes, uint32_t nnodes, const Geom* geom, uint32_t* arr
 void launch_refit8(Node8* nodes, uint32_t nnodes, const Geom* geom, uint32_t* arrive, float* root_box, int grow_only,
                    hipStream_t s);
 void launch_slots_to_scene(const int32_t* slots, const uint32_t* sidx, int32_t* out, uint32_t n, hipStream_t s);
+void launch_powf_probe(const float* x, const float* y, uint32_t n, float* out, hipStream_t s);
 void launch_pack_rays(const float* org_dir, uint32_t n, float4* rayO, float4* rayD, bool shadow, hipStream_t s);
 void launch_tiles_copy(const FrameParams& fp, const uint32_t* tile_ids, int ntiles, const uint8_t* src, uint8_t* dst,
                        int to_packed, hipStream_t s);

@@ -1199,8 +1199,127 @@ __constant__ WallDef c_walls[6] = {
     {{0, -1, 0}, {0, 200.0f, 0}, 0, {0.9f, 0.9f, 0.9f}, {1.0f, 1.0f, 1.0f}},
 };
 
+/* ------------------------------------------------------------------------------------------
+ * powf as the host's libm computes it.  Shade's specular term is pow(dot, shininess) on floats (Ray.cu:655); the parity
+ * target (oracle/, and any host build of the reference) evaluates it with glibc's powf.  Until round 2 the kernel called
+ * the device's double-precision pow and rounded -- correct to the last bit in practice, and most of k_shade's instructions.
+ * This is glibc 2.35's algorithm restated (sysdeps/ieee754/flt-32/e_powf.c: log2 by a 16-entry table and a degree-5
+ * polynomial, exp2 by a 32-entry table and a cubic, all in double), with the multiply-adds fused where the x86-64 FMA build
+ * of libm fuses them: bit-identical to the host's powf on 10^8 random (dot, shininess) pairs, subnormal results included
+ * (tools/exp/powf_check.c; the unfused variant differs once in 10^8), and on the special values (zeros, infinities, NaNs,
+ * subnormal bases, negative bases) whose branches are restated too.  Measured: k_shade is not bound by it either way
+ * (1.66 ms per frame with the device's pow, 1.60 with no pow at all, 1.67 with this) -- the point is that the term is now
+ * the parity target's own arithmetic instead of "correct to the last bit in practice".
+ * ------------------------------------------------------------------------------------------ */
+/* constants of glibc 2.35 powf (sysdeps/ieee754/flt-32/e_powf.c, powf_log2_data.c, exp2f_data.c; S. Nagy, ARM optimized routines) */
+static __device__ const double d_powlog2_tab[16][2] = {
+    {0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2},
+    {0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2},
+    {0x1.49539f0f010b0p+0, -0x1.7418b0a1fb77bp-2},
+    {0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2},
+    {0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2},
+    {0x1.25e227b0b8ea0p+0, -0x1.97c1d1b3b7af0p-3},
+    {0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3},
+    {0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4},
+    {0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5},
+    {0x1.0000000000000p+0, 0x0.0p+0},
+    {0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4},
+    {0x1.ca4b31f026aa0p-1, 0x1.476a9543891bap-3},
+    {0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3},
+    {0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2},
+    {0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2},
+    {0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2},
+};
+static __device__ const double d_powlog2_poly[5] = {0x1.27616c9496e0bp-2, -0x1.71969a075c67ap-2, 0x1.ec70a6ca7baddp-2, -0x1.7154748bef6c8p-1, 0x1.71547652ab82bp+0};
+static __device__ const unsigned long long d_exp2f_tab[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull,
+};
+static __device__ const double d_exp2f_poly[3] = {0x1.c6af84b912394p-5, 0x1.ebfce50fac4f3p-3, 0x1.62e42ff0c52d6p-1};
+
+/* ltab / etab: the two tables, in LDS for k_shade (a global gather costs two dependent cache round trips per call) */
+CRT_DEV int powf_checkint(uint32_t iy) {          /* 0: not an integer, 1: odd, 2: even (e_powf.c checkint) */
+    const int e = (int)(iy >> 23 & 0xffu);
+    if (e < 0x7f) return 0;
+    if (e > 0x7f + 23) return 2;
+    if (iy & ((1u << (0x7f + 23 - e)) - 1u)) return 0;
+    return (iy & (1u << (0x7f + 23 - e))) ? 1 : 2;
+}
+CRT_DEV float powf_libm(float x, float y, const double (*ltab)[2] = d_powlog2_tab, const unsigned long long* etab = d_exp2f_tab) {
+    uint32_t ix = __float_as_uint(x), sign_bias = 0;
+    const uint32_t iy = __float_as_uint(y);
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u || 2u * iy - 1u >= 2u * 0x7f800000u - 1u) {
+        /* either (x < 0x1p-126 or inf or nan) or (y is 0 or inf or nan): e_powf.c's special cases, in its order */
+        if (2u * iy - 1u >= 2u * 0x7f800000u - 1u) {
+            if (2u * iy == 0u) return 1.0f;
+            if (ix == 0x3f800000u) return 1.0f;
+            if (2u * ix > 2u * 0x7f800000u || 2u * iy > 2u * 0x7f800000u) return x + y;
+            if (2u * ix == 2u * 0x3f800000u) return 1.0f;
+            if ((2u * ix < 2u * 0x3f800000u) == !(iy & 0x80000000u)) return 0.0f;      /* |x| < 1 && y == inf, or |x| > 1 && y == -inf */
+            return y * y;
+        }
+        if (2u * ix - 1u >= 2u * 0x7f800000u - 1u) {
+            float x2 = x * x;
+            if ((ix & 0x80000000u) && powf_checkint(iy) == 1) x2 = -x2;
+            return (iy & 0x80000000u) ? 1.0f / x2 : x2;
+        }
+        if (ix & 0x80000000u) {                       /* finite x < 0: needs an integer y */
+            const int yint = powf_checkint(iy);
+            if (yint == 0) return __uint_as_float(0x7fc00000u);
+            if (yint == 1) sign_bias = 1u << (5 + 11);
+            ix &= 0x7fffffffu;
+        }
+        if (ix < 0x00800000u) {                       /* subnormal x: normalise, the exponent goes negative */
+            ix = __float_as_uint(__uint_as_float(ix) * 0x1p23f);
+            ix &= 0x7fffffffu;
+            ix -= 23u << 23;
+        }
+    }
+    /* log2_inline: x = 2^k z, z in [OFF, 2 OFF), c near the centre of z's subinterval: log2(x) = log1p(z/c - 1)/ln2 + log2(c) + k */
+    const uint32_t tmp = ix - 0x3f330000u;
+    const uint32_t i = (tmp >> (23 - 4)) & 15u;
+    const uint32_t top = tmp & 0xff800000u;
+    const int k = (int32_t)top >> 23;
+    const double z = (double)__uint_as_float(ix - top);
+    const double r = fma(z, ltab[i][0], -1.0);
+    const double y0 = ltab[i][1] + (double)k;
+    const double r2 = r * r;
+    double yy = fma(d_powlog2_poly[0], r, d_powlog2_poly[1]);
+    const double p = fma(d_powlog2_poly[2], r, d_powlog2_poly[3]);
+    const double r4 = r2 * r2;
+    double q = fma(d_powlog2_poly[4], r, y0);
+    q = fma(p, r2, q);
+    yy = fma(yy, r4, q);
+    const double ylogx = (double)y * yy;
+    if (((unsigned long long)__double_as_longlong(ylogx) >> 47 & 0xffffull) >= ((unsigned long long)__double_as_longlong(126.0) >> 47)) {
+        if (ylogx > 0x1.fffffffd1d571p+6) return __uint_as_float((sign_bias ? 0x80000000u : 0u) | 0x7f800000u);
+        if (ylogx <= -150.0) return __uint_as_float(sign_bias ? 0x80000000u : 0u);
+    }
+    /* exp2_inline: ylogx = k/32 + r, |r| <= 1/64; 2^(k/32) from the table with the exponent added into its bits */
+    const double shift = 0x1.8p+47;
+    double kd = ylogx + shift;
+    const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+    kd -= shift;
+    const double rr = ylogx - kd;
+    unsigned long long t = etab[ki & 31ull];
+    t += (ki + sign_bias) << (52 - 5);
+    const double sc = __longlong_as_double((long long)t);
+    const double zz = fma(d_exp2f_poly[0], rr, d_exp2f_poly[1]);
+    const double rr2 = rr * rr;
+    double w = fma(d_exp2f_poly[2], rr, 1.0);
+    w = fma(zz, rr2, w);
+    w = w * sc;
+    return (float)w;
+}
+
 #ifndef CRT_SHADE_MIN_WAVES
-#define CRT_SHADE_MIN_WAVES 4          /* 128 VGPRs (28 bytes of spill) instead of 131: 4 waves per SIMD, shade+resolve 1.87 -> 1.67 ms per frame; 5 and 6 spill too much */
+#define CRT_SHADE_MIN_WAVES 4          /* a floor only: with powf_libm instead of the device's double pow the kernel needs 93 VGPRs, no scratch (128 + 28 B before), i.e. 5 waves per SIMD; forcing 6 (79 VGPRs, 44 B of spill) gains 2 %, 8 loses 60 % */
 #endif
 #if CRT_SHADE_MIN_WAVES > 0
 #define CRT_SHADE_BOUNDS __launch_bounds__(256, CRT_SHADE_MIN_WAVES)
@@ -1213,6 +1332,10 @@ __global__ CRT_SHADE_BOUNDS void k_shade(FrameParams P, FrameBuffers B, SceneVie
      * queue): per-wave atomics on the two counters made this kernel atomic-bound */
     __shared__ uint32_t s_cnt[2][4];
     __shared__ uint32_t s_base[2];
+    __shared__ double s_ltab[16][2];
+    __shared__ unsigned long long s_etab[32];
+    if (threadIdx.x < 32) { reinterpret_cast<double*>(s_ltab)[threadIdx.x] = reinterpret_cast<const double*>(d_powlog2_tab)[threadIdx.x]; s_etab[threadIdx.x] = d_exp2f_tab[threadIdx.x]; }
+    __syncthreads();
     const uint32_t total = *count;
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t rounded = (total + 255u) & ~255u;
@@ -1385,7 +1508,7 @@ __global__ CRT_SHADE_BOUNDS void k_shade(FrameParams P, FrameBuffers B, SceneVie
                     }
                     sorg = intersection;
                     const float sdot = dot(reflect(reflectFromLight, N), -direction);
-                    const float spec = (float)pow((double)sdot, (double)shininess);
+                                        const float spec = powf_libm(sdot, shininess, s_ltab, s_etab);
                     const vec3 X = (.6f * diffuse * gmax(dot(toLight, N), 0.0f) + .2f * specular * spec);
                     B.contrib[plane] = make_float4(X.x, X.y, X.z, distance);
                     B.shflag[plane] = flag;
@@ -1712,6 +1835,14 @@ __global__ void k_slots_to_scene(const int32_t* slots, const uint32_t* sidx, int
 void launch_slots_to_scene(const int32_t* slots, const uint32_t* sidx, int32_t* out, uint32_t n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_slots_to_scene, dim3((n + 255) / 256), dim3(256), 0, s, slots, sidx, out, n);
 }
+__global__ void k_powf_probe(const float* x, const float* y, uint32_t n, float* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = powf_libm(x[i], y[i]);
+}
+void launch_powf_probe(const float* x, const float* y, uint32_t n, float* out, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_powf_probe, dim3((n + 255) / 256), dim3(256), 0, s, x, y, n, out);
+}
+
 __global__ void k_pack_rays(const float* od, uint32_t n, float4* rayO, float4* rayD, uint32_t dw) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

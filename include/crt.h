@@ -183,6 +183,10 @@ int crt_trace(crt_ctx*, const float* org_dir /* 6n host floats */, int n, int32_
 /* shadow predicate of Ray.cu:650-656 for directional lights: out[i]=1 iff a hit exists and the
  * nearest hit has t > 1e-9 */
 int crt_trace_shadow(crt_ctx*, const float* org_dir, int n, uint8_t* shadowed_out);
+/* pow(x, y) as Shade's specular term evaluates it on the device (Ray.cu:655 `pow(dot(...), shininess)` on floats), n values,
+ * host arrays.  Parity hook without a counterpart in the reference: the kernel restates the host libm's powf and the
+ * tests hold it against the oracle's, value by value. */
+int crt_powf_probe(crt_ctx*, const float* x, const float* y, int n, float* out);
 /* crt_trace for callers that cannot allocate.  No counterpart in the reference (like crt_trace itself); it exists for
  * code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc: crt_trace allocates and frees
  * its working buffers on every call, this entry point calls no hipMalloc / hipFree / event or other allocating

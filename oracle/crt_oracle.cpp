@@ -715,6 +715,10 @@ int orc_wall(const float o[3], const float d[3], int raytype, const float coef_i
     return w;
 }
 
+void orc_powf(const float* x, const float* y, int n, float* out) {
+    for (int i = 0; i < n; i++) out[i] = powf(x[i], y[i]);
+}
+
 /* Probe of the vec3 restatement, compared bit-for-bit with the vendored GLM by oracle/ref_driver.cpp.
  * in: n rows of 9 floats (a, b, c); out: n rows of ORC_PROBE_W floats. */
 void orc_math_probe(const float* in, int n, float* out) {

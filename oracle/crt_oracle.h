@@ -119,6 +119,9 @@ void orc_stats_reset(orc_scene*);
 #define ORC_PROBE_W 32
 void orc_math_probe(const float* in9, int n, float* out32);
 
+/* powf exactly as Shade's specular term calls it (Ray.cu:655), value by value: what the device's restatement is held against */
+void orc_powf(const float* x, const float* y, int n, float* out);
+
 /* ---- OBJ loader (objloader.cpp:20-112) ---- */
 /* returns number of corners written (3 per face) or -1; pass NULL outputs to query the count. */
 int orc_load_obj(const char* path, float* verts3, float* norms3, int max_corners);

@@ -69,7 +69,7 @@ def lib():
             "orc_scene_get": [vp, vp], "orc_scene_set": [vp, vp], "orc_refit": [vp], "orc_animate": [vp],
             "orc_trace": [vp, vp, i, vp, vp, vp, vp, i], "orc_trace_brute": [vp, vp, i, vp, vp, i],
             "orc_primary_rays": [vp, vp, i, i, vp], "orc_stats_get": [vp, vp], "orc_stats_reset": [vp],
-            "orc_math_probe": [vp, i, vp], "orc_area_table": [vp, i],
+            "orc_math_probe": [vp, i, vp], "orc_area_table": [vp, i], "orc_powf": [vp, vp, i, vp],
         }.items():
             getattr(L, name).restype = None
             getattr(L, name).argtypes = args
@@ -113,6 +113,14 @@ def math_probe(in9):
     in9 = np.ascontiguousarray(in9, np.float32).reshape(-1, 9)
     out = np.zeros((len(in9), 32), np.float32)
     lib().orc_math_probe(_p(in9), len(in9), _p(out))
+    return out
+
+
+def powf(x, y):
+    """libm powf of the host, value by value (the call of Shade's specular term, Ray.cu:655)"""
+    x = np.ascontiguousarray(x, np.float32); y = np.ascontiguousarray(y, np.float32)
+    out = np.zeros(x.shape, np.float32)
+    lib().orc_powf(_p(x), _p(y), x.size, _p(out))
     return out
 
 
