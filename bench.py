@@ -132,10 +132,14 @@ def cpu_baseline(prims, lights, cam, tgt, width, height, bounces, max_threads):
     tp.render(lights, cam, tgt, 720, 360, 1, nthreads=cores)
     dt0 = time.perf_counter() - t0
     st0 = tp.stats(reset=True)
+    t1 = time.perf_counter()
+    tp.render(lights, cam, tgt, 720, 360, 1, nthreads=1)          # once single-threaded, once on all cores
+    dt1 = time.perf_counter() - t1
     tp.close()
     return {
         "reference_case": {"workload": "configs[0]: teapot3.obj + sphere, 720x360, bounces=1, whole frame", "value": round(st0["traversals"] / dt0 / 1e6, 3),
-                           "unit": "Mrays/s", "frame_ms": round(dt0 * 1e3, 2), "traversals": st0["traversals"], "cores": cores},
+                           "unit": "Mrays/s", "frame_ms": round(dt0 * 1e3, 2), "traversals": st0["traversals"], "cores": cores,
+                           "single_thread": {"value": round(st0["traversals"] / dt1 / 1e6, 3), "frame_ms": round(dt1 * 1e3, 1)}},
         "value": round(st["traversals"] / dt / 1e6, 6), "unit": "Mrays/s", "cores": cores, "kind": "port",
         "sample": f"centred {rect[2] - rect[0]}x{rect[3] - rect[1]} sub-rectangle of the {width}x{height} frame, "
                   f"bounces={bounces}: {st['traversals']} traversals issued by the reference's logic "
