@@ -191,12 +191,12 @@ __device__ __forceinline__ void load_box(float4 (&pre)[2 * kBox], const float4* 
  *   waves 1, 2  the child's box over the same tile: min/max are exact in any order (bvh.cu:70-129).
  * Tiles start at a multiple of 4 elements below the child's first position so that the 128-bit loads are aligned; elements
  * outside the child are replaced by -0.0f, the identity of float addition (x + -0 = x for every x). */
-__global__ __launch_bounds__(192) void k_rr_children(const Seg* kids, uint32_t nkids, const float* cx, const float* cy, const float* cz,
+__global__ __launch_bounds__(192) void k_rr_children(const Seg* kids, const uint32_t* nseg_this_level, const float* cx, const float* cy, const float* cz,
                                                       const float4* lo, const float4* hi, Seg* next, uint32_t* next_count, uint32_t* slotmap) {
     __shared__ __align__(16) float s_c[2][3][kTile];
     __shared__ float s_box[2][6];
     const uint32_t k = blockIdx.x;
-    if (k >= nkids) return;
+    if (k >= 2u * *nseg_this_level) return;            /* the grid is an upper bound when the host skipped a read-back */
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t start = kids[k].start, count = kids[k].count;
     if (count <= (uint32_t)kLeafMax) {                 /* a leaf: needs neither box nor midpoint */
@@ -328,8 +328,16 @@ int refrank_build(void* scratch, const crt_prim* d_prims, uint32_t n, const floa
     }
     hipLaunchKernelGGL(k_rr_init, dim3(blocks), dim3(256), 0, s, d_prims, n, S.cen[0][0], S.cen[0][1], S.cen[0][2], S.lo[0], S.hi[0],
                        S.order[0], S.segid[0], nseg ? 0u : kNone);
-    uint32_t level = 0;
-    while (nseg > 0) {
+    /* S.ctr[0], S.ctr[1]: the number of segments of this level and of the next, alternating.  The host needs the count for
+     * the grid of k_rr_children and to know when to stop; a read-back is a stream synchronisation (~40 us), which for a
+     * small scene is most of the pass, so there it is taken only every fourth level: the grid is then the bound
+     * min(2 x last known count x 2^levels since, n / 32 + 2) and a level without segments is a handful of empty launches. */
+    RR(hipMemcpyAsync(S.ctr + 0, &nseg, 4, hipMemcpyHostToDevice, s));
+    const uint32_t kid_cap = n / 32u + 2u;
+    const int readback_every = n >= 200000u ? 1 : 4;
+    uint32_t level = 0, bound = nseg;                  /* bound >= the true count */
+    int cbuf = 0, since = 0;
+    while (bound > 0) {
         if (++level > 257) {       /* level L splits the nodes of depth L-1; bvh_build.cpp gives up beyond depth 256 */
             RR(hipStreamSynchronize(s));
             if (err) *err = "refrank_build: the reference's split does not terminate on this scene";
@@ -344,13 +352,18 @@ int refrank_build(void* scratch, const crt_prim* d_prims, uint32_t n, const floa
                            S.cen[cur][0], S.cen[cur][1], S.cen[cur][2], S.lo[cur], S.hi[cur], S.order[cur],
                            S.cen[nxt][0], S.cen[nxt][1], S.cen[nxt][2], S.lo[nxt], S.hi[nxt], S.order[nxt], S.segid[nxt], S.kids);
         cur = nxt;
-        RR(hipMemsetAsync(S.ctr, 0, 4, s));
-        hipLaunchKernelGGL(k_rr_children, dim3(2u * nseg), dim3(192), 0, s, S.kids, 2u * nseg, S.cen[cur][0], S.cen[cur][1], S.cen[cur][2],
-                           S.lo[cur], S.hi[cur], S.segs[segbuf ^ 1], S.ctr, S.slotmap);
-        segbuf ^= 1;
-        RR(hipMemcpyAsync(&nseg, S.ctr, 4, hipMemcpyDeviceToHost, s));
-        RR(hipStreamSynchronize(s));
+        RR(hipMemsetAsync(S.ctr + (cbuf ^ 1), 0, 4, s));
+        const uint32_t kids_bound = 2u * bound < kid_cap ? 2u * bound : kid_cap;
+        hipLaunchKernelGGL(k_rr_children, dim3(kids_bound), dim3(192), 0, s, S.kids, S.ctr + cbuf, S.cen[cur][0], S.cen[cur][1], S.cen[cur][2],
+                           S.lo[cur], S.hi[cur], S.segs[segbuf ^ 1], S.ctr + (cbuf ^ 1), S.slotmap);
+        segbuf ^= 1; cbuf ^= 1;
+        if (++since >= readback_every) {
+            RR(hipMemcpyAsync(&nseg, S.ctr + cbuf, 4, hipMemcpyDeviceToHost, s));
+            RR(hipStreamSynchronize(s));
+            bound = nseg; since = 0;
+        } else bound = kids_bound;
     }
+    level -= (uint32_t)since;      /* levels launched after the last read-back that found segments may have been empty */
     hipLaunchKernelGGL(k_rr_ranks, dim3(blocks), dim3(256), 0, s, S.order[cur], n, d_rank_of_scene);
     RR(hipGetLastError());
     if (h_levels) *h_levels = level;
