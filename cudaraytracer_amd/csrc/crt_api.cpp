@@ -88,6 +88,7 @@ struct crt_ctx {
     void* d_refrank = nullptr; size_t refrank_cap = 0;          /* scratch of the device-side reference-order pass */
     uint32_t* d_refrank_out = nullptr; size_t refrank_out_cap = 0; bool dev_rank_valid = false; uint32_t refrank_levels = 0;
     uint32_t* d_status = nullptr;
+    bool ev_error = false;             /* a timing event could not be created or recorded since the last render call began */
     uint32_t* h_status = nullptr;      /* pinned: crt_trace_noalloc reads the status word without a staging copy */
     void* noalloc_scratch = nullptr;   /* this device's copy of noalloc.hip's scratch array (address looked up once per device) */
     unsigned long long* d_testctr = nullptr;
@@ -216,15 +217,26 @@ void scene_abs_from_box(crt_ctx* c) {
     c->scene_abs = m;
 }
 
+/* events come from a pool that only grows; a failure to create or record one is remembered (ev_error) and reported by
+ * the call that was timing with it */
+bool reserve_events(crt_ctx* c, size_t k) {          /* the next k calls of next_event() cannot fail afterwards */
+    while (c->evpool.size() < c->evused + k) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); c->ev_error = true; return false; }
+        c->evpool.push_back(e);
+    }
+    return true;
+}
 hipEvent_t next_event(crt_ctx* c) {
-    if (c->evused == c->evpool.size()) { hipEvent_t e; hipEventCreate(&e); c->evpool.push_back(e); }
+    if (!reserve_events(c, 1)) return nullptr;
     return c->evpool[c->evused++];
 }
 enum { EV_START = 0, EV_GEN, EV_TRACE_N, EV_SHADE, EV_TRACE_S, EV_RESOLVE, EV_CONVERT, EV_SORT, EV_TRACE_M };
 void mark(crt_ctx* c, int kind) {
     if (c->in_capture) return;             /* per-kernel timing is not available for a replayed graph */
     hipEvent_t e = next_event(c);
-    hipEventRecord(e, c->stream);
+    if (!e) return;
+    if (hipEventRecord(e, c->stream) != hipSuccess) { c->ev_error = true; c->evused--; return; }
     c->evlog.emplace_back(kind, (int)c->evused - 1);
 }
 
@@ -650,6 +662,7 @@ int crt_bvh_refit(crt_ctx* c, int grow_only) {
     if (!c->built) return fail(c, CRT_ERR_STATE, "crt_bvh_refit: no BVH (call crt_bvh_build)");
     HIPCHECK(c, hipSetDevice(c->device));
     char* b = (char*)c->d_blob;
+    if (!reserve_events(c, 2)) return fail(c, CRT_ERR_HIP, "crt_bvh_refit: hipEventCreate failed");
     hipEvent_t e0 = next_event(c), e1 = next_event(c);
     c->evused -= 2;
     HIPCHECK(c, hipEventRecord(e0, c->stream));
@@ -830,7 +843,7 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
         HIPCHECK(c, hipMemsetD32Async((hipDeviceptr_t)c->cap_ids, -9, (size_t)p->bounces * npix, c->stream));
         HIPCHECK(c, hipMemsetD32Async((hipDeviceptr_t)c->cap_ts, 0, (size_t)p->bounces * npix, c->stream));
     }
-    c->evused = 0; c->evlog.clear();
+    c->evused = 0; c->evlog.clear(); c->ev_error = false;
     const SceneView sv = view_of(c);
     /* the slab-test pad scales with the scene's extent, a kernel argument: a replayed graph keeps the value it was
      * captured with, so graph mode rounds it up to a power of two (a larger pad is as conservative) and re-captures
@@ -958,6 +971,7 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     rc = check_status(c);
     if (rc) return rc;
+    if (c->ev_error || c->evlog.size() < 2) return fail(c, CRT_ERR_HIP, "render: a timing event could not be created or recorded (the frame itself is complete)");
 
     crt_stats& st = c->stats;
     st.rays_primary = st.rays_shadow = st.rays_reflect = 0;
@@ -1042,6 +1056,7 @@ int crt_render(crt_ctx* c, const crt_camera* cam, const crt_params* p, unsigned 
     const size_t chunk = ((bytes + kChunks - 1) / kChunks + 4095) & ~(size_t)4095;
     hipEvent_t ev[kChunks];
     int nchunks = 0;
+    if (!reserve_events(c, (size_t)kChunks)) return fail(c, CRT_ERR_HIP, "crt_render: hipEventCreate failed");
     for (size_t off = 0; off < bytes; off += chunk, nchunks++) {
         const size_t len = off + chunk < bytes ? chunk : bytes - off;
         ev[nchunks] = next_event(c);
@@ -1116,6 +1131,7 @@ static int trace_hook(crt_ctx* c, const float* org_dir, int n, int32_t* prim_out
             ta.shO = d_o; ta.shD = d_d; ta.shcount = d_cnt;
             ta.rayO = nullptr; ta.rayD = nullptr; ta.count = nullptr;
         }
+        if (!reserve_events(c, 2)) { c->err = "crt_trace: hipEventCreate failed"; rc = CRT_ERR_HIP; goto done; }
         hipEvent_t e0 = next_event(c), e1 = next_event(c);
         c->evused -= 2;
         TH(hipEventRecord(e0, c->stream));
