@@ -161,6 +161,7 @@ def main():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--bounces", type=int, default=3)
     ap.add_argument("--spp", type=int, default=None)
+    ap.add_argument("--no-pipeline", action="store_true", help="N>1: finish every frame's tile gather before the next frame starts")
     ap.add_argument("--bvh", type=int, default=0, help="0 wide SAH built on the host (default), 1 reference topology, 2 wide LBVH built on the device")
     ap.add_argument("--sort-rays", type=int, default=0, help="1: visit secondary rays in Morton order of their origin cell")
     ap.add_argument("--weak", action="store_true", help="N > 1: grow the frame with N at a fixed pixel count per GPU (weak scaling) "
@@ -225,10 +226,13 @@ def main():
         sr.broadcast_scene(prims, lights, a.bvh)
         ctx = sr.ctx
 
+        # throughput mode: the tile gather of frame k runs under the render of frame k+1 (double-buffered frames); the fence
+        # completes the frame still in flight, so the timed region holds exactly K finished frames
         def step():
-            sr.render(cam, tgt, params, phase)
+            sr.render(cam, tgt, params, phase, pipelined=not a.no_pipeline)
 
         def fence():
+            sr.finish()
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()

@@ -89,9 +89,14 @@ class ShardedRenderer:
         # RCCL gathers device tensors directly; gloo (the one-GPU rehearsal) has no device gather, so stage through the host
         self.host_gather = dist.get_backend() != "nccl"
         self.frame = None
+        self.frames = None          # two device frames (pipelined mode alternates), packed-tile and gather buffers alike
+        self.packs = None
+        self.gathers = None
         self.packed = None
         self.gathered = None
         self.sizes = None
+        self.pending = None         # pipelined mode: (params, buffer index, collective work, keep-alive) of the frame in flight
+        self.flip = 0
 
     def _bcast_bytes(self, payload):
         """broadcast a bytes-like object from rank 0 (device tensors: RCCL has no host path)"""
@@ -158,49 +163,89 @@ class ShardedRenderer:
     def _ensure(self, params):
         torch = self.torch
         npix = params.width * params.height
-        if self.frame is None or self.frame.numel() != npix * 3:
-            self.frame = torch.zeros(npix * 3, dtype=torch.uint8, device=self.dev)
+        if self.frames is None or self.frames[0].numel() != npix * 3:
+            self.frames = [torch.zeros(npix * 3, dtype=torch.uint8, device=self.dev) for _ in range(2)]
+            self.frame = self.frames[0]
         sizes = [packed_nbytes(params, r) for r in range(self.world)]
         if self.sizes != sizes:
+            self.finish()
             self.sizes = sizes
             mx = max(sizes)
-            self.packed = torch.zeros(mx, dtype=torch.uint8, device=self.dev)
-            self.gathered = [torch.zeros(mx, dtype=torch.uint8, device=self.dev) for _ in range(self.world)] \
-                if self.rank == 0 else None
+            self.packs = [torch.zeros(mx, dtype=torch.uint8, device=self.dev) for _ in range(2)]
+            self.gathers = [[torch.zeros(mx, dtype=torch.uint8, device=self.dev) for _ in range(self.world)] for _ in range(2)] \
+                if self.rank == 0 else [None, None]
+            self.packed, self.gathered = self.packs[0], self.gathers[0]
 
-    def render(self, cam, target, params, phase=None):
+    def _gather(self, packed, gathered, async_op):
+        """gather of the packed tiles to rank 0; returns (work or None, keepalive)"""
+        if self.host_gather:      # gloo rehearsal: no device gather, stage through the host
+            mine = packed.cpu()
+            got = [self.torch.zeros_like(mine) for _ in range(self.world)] if self.rank == 0 else None
+            w = self.dist.gather(mine, got, dst=0, async_op=async_op)
+            return w, (mine, got)
+        w = self.dist.gather(packed, gathered, dst=0, async_op=async_op)
+        return w, None
+
+    def _complete(self, params, k, work, keep):
+        """wait for gather k and scatter the other ranks' tiles into frame k (rank 0)"""
+        if work is not None:
+            work.wait()
+        if self.host_gather and self.rank == 0:
+            for r in range(1, self.world):
+                self.gathers[k][r].copy_(keep[1][r])
+        # every rank waits for its part of the gather: a later frame packs into the same buffer on another stream
+        self.torch.cuda.synchronize(self.dev)
+        if self.rank == 0:
+            for r in range(1, self.world):
+                self.ctx.tiles_unpack(params, r, self.gathers[k][r].data_ptr(), self.frames[k].data_ptr())
+            self.ctx.sync()
+
+    def finish(self):
+        """pipelined mode: complete the frame whose gather is still in flight; returns it on rank 0"""
+        if self.pending is None:
+            return None
+        params, k, work, keep = self.pending
+        self.pending = None
+        self._complete(params, k, work, keep)
+        return self.frames[k] if self.rank == 0 else None
+
+    def render(self, cam, target, params, phase=None, pipelined=False):
         """Render this rank's tiles, gather to rank 0.  Returns the device frame tensor on rank 0.
-        `phase` (optional dict) accumulates this rank's wall seconds per phase: render, pack, gather, unpack."""
+        `phase` (optional dict) accumulates this rank's wall seconds per phase: render, pack, gather, unpack.
+
+        pipelined=True: the gather of frame k runs (asynchronously, on the collective's own stream) under the render of
+        frame k+1 -- frames, packed tiles and gather buffers are double buffered -- and the call returns the PREVIOUS
+        frame, complete, or None on the first call; finish() completes the last one.  Throughput mode for bench.py:
+        a step then costs max(render, exchange) instead of their sum."""
         import time
         params.rank, params.nranks = self.rank, self.world
         self._ensure(params)
+        k = self.flip if pipelined else 0
+        self.frame = self.frames[k]
         t0 = time.perf_counter()
-        self.ctx.render_device(cam, target, params, self.frame.data_ptr())       # returns with the frame complete
+        self.ctx.render_device(cam, target, params, self.frames[k].data_ptr())       # returns with the frame complete
         t1 = time.perf_counter()
         if phase is not None:
             phase["render"] = phase.get("render", 0.0) + (t1 - t0)
         if self.world == 1:
-            return self.frame
-        self.ctx.tiles_pack(params, self.frame.data_ptr(), self.packed.data_ptr())     # returns with the copy finished
+            return self.frames[k]
+        prev = self.finish() if pipelined else None      # frame k-1: its gather ran under this frame's render
+        t1b = time.perf_counter()
+        self.ctx.tiles_pack(params, self.frames[k].data_ptr(), self.packs[k].data_ptr())     # returns with the copy finished
         t2 = time.perf_counter()
-        if self.host_gather:
-            mine = self.packed.cpu()
-            got = [self.torch.zeros_like(mine) for _ in range(self.world)] if self.rank == 0 else None
-            self.dist.gather(mine, got, dst=0)
-            if self.rank == 0:
-                for r in range(1, self.world):
-                    self.gathered[r].copy_(got[r])
-        else:
-            self.dist.gather(self.packed, self.gathered, dst=0)
-        # every rank waits for its part of the gather: the next frame packs into the same buffer on another stream
-        self.torch.cuda.synchronize(self.dev)
+        work, keep = self._gather(self.packs[k], self.gathers[k], async_op=pipelined)
+        if pipelined:
+            self.pending = (api.Params.from_buffer_copy(params), k, work, keep)
+            self.flip ^= 1
+            t3 = time.perf_counter()
+            if phase is not None:
+                phase["pack"] = phase.get("pack", 0.0) + (t2 - t1b)
+                phase["gather"] = phase.get("gather", 0.0) + (t1b - t1) + (t3 - t2)      # exposed part: wait for k-1 + issue of k
+            return prev
         t3 = time.perf_counter()
-        if self.rank == 0:
-            for r in range(1, self.world):
-                self.ctx.tiles_unpack(params, r, self.gathered[r].data_ptr(), self.frame.data_ptr())
-            self.ctx.sync()
+        self._complete(params, k, None, keep)
         if phase is not None:
             phase["pack"] = phase.get("pack", 0.0) + (t2 - t1)
             phase["gather"] = phase.get("gather", 0.0) + (t3 - t2)
             phase["unpack"] = phase.get("unpack", 0.0) + (time.perf_counter() - t3)
-        return self.frame if self.rank == 0 else None
+        return self.frames[k] if self.rank == 0 else None

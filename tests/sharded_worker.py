@@ -25,11 +25,14 @@ def main():
     sr.broadcast_scene(prims, crt.default_lights() if rank == 0 else None, mode, animated=frames > 0)
     cam, tgt = crt.default_camera()
     p = crt.default_params(width=w, height=h, bounces=bounces)
+    pipelined = os.environ.get("CRT_TEST_PIPELINED") == "1"      # the gather of frame k under the render of frame k+1
     for _ in range(2):                                   # twice: buffers and tile lists are reused
-        frame = sr.render(cam, tgt, p)
+        frame = sr.render(cam, tgt, p, pipelined=pipelined)
     for f in range(1, frames + 1):                       # replicated animation: refit, every 4th step a device rebuild
         sr.animate(rebuild=(f % 4 == 0))
-        frame = sr.render(cam, tgt, p)
+        frame = sr.render(cam, tgt, p, pipelined=pipelined)
+    if pipelined:
+        frame = sr.finish()                              # render() returned the frame before; this is the last one
     if rank == 0:
         np.save(out, frame.cpu().numpy().reshape(h, w, 3))
     dist.barrier()

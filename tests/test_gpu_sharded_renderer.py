@@ -32,14 +32,16 @@ def test_sharded_renderer_gathers_the_single_gpu_frame(tmp_path, world, mode):
     assert np.array_equal(np.load(out), full)
 
 
-def test_sharded_renderer_animates_on_every_rank(tmp_path):
+@pytest.mark.parametrize("pipelined", [0, 1])
+def test_sharded_renderer_animates_on_every_rank(tmp_path, pipelined):
     """SURVEY 8(e) collective (2): the ranks replicate the deterministic animation step (crt_animate_device) on the
     scene they were handed once, refit locally, rebuild on the device every 4th step; the gathered frame after 6
-    steps equals one GPU doing the same."""
+    steps equals one GPU doing the same.  pipelined: the tile gather of a frame runs under the render of the next
+    (bench.py's throughput mode, double-buffered frames) -- the last frame, completed by finish(), is the same."""
     import cudaraytracer_amd as crt
     world, mode, w, h, bounces, frames = 2, 0, 300, 200, 2, 6
     out = str(tmp_path / "anim.npy")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE=str(world))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29541 + pipelined), WORLD_SIZE=str(world), CRT_TEST_PIPELINED=str(pipelined))
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), out, str(w), str(h), str(bounces), str(mode), str(frames)],
                               env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     logs = [p.communicate(timeout=600)[0] for p in procs]
