@@ -28,6 +28,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 N_SIMD = 256 * 4          # 256 CUs x 4 SIMDs
+SPEC_CLOCK_GHZ = 2.4      # MI355X peak engine clock
 UBENCH_VALU = os.path.join(ROOT, "profiles", "r02_ubench_valu_issue.jsonl")    # tools/ubench/valu_issue.hip on MI355X
 UBENCH_L1 = os.path.join(ROOT, "profiles", "r02_ubench_l1_gather.jsonl")       # tools/ubench/l1_gather.hip on MI355X
 ISA_MIX = os.path.join(ROOT, "cudaraytracer_amd", "isa_mix_k_trace8.json")     # tools/isa_mix.py, written by the build
@@ -64,7 +65,7 @@ def valu_issue_model(cst):
 
     def reg(name):
         r = R.get(name, {"valu": 0, "valu_issue_cycles": 0.0})
-        return np.array([r["valu"], r["valu_issue_cycles"]], np.float64)
+        return np.array([r["valu"], r["valu_issue_cycles"], r.get("valu_issue_cycles_nominal", r["valu_issue_cycles"])], np.float64)
     it, node, prim = cst["sched_iterations"], cst["sched_node_iterations"], cst["sched_prim_iterations"]
     sph = prim if cst["sph_tests"] + cst["sph_tests_shadow"] > 0 else 0
     times = {"prologue": cst["trace_waves"], "refill1": cst["sched_refill_iterations"], "between_refill1": it, "vote": it, "between_vote": it,
@@ -75,7 +76,7 @@ def valu_issue_model(cst):
              # the tail instantiation of the loop (queue dry, work sharing): its iterations are in the node / primitive / finish
              # counts above and are priced with the main loop's regions; the region itself is the second copy of the code
              "tail": 0, "between_tail": 0}
-    tot = np.zeros(2)
+    tot = np.zeros(3)
     mix["breakdown"] = {}
     for name in R:
         if name not in times:
@@ -84,7 +85,7 @@ def valu_issue_model(cst):
         if times[name] and R[name]["valu"]:
             mix["breakdown"][name] = {"executions": int(times[name]), "valu_per_execution": R[name]["valu"],
                                       "issue_cycles_per_execution": R[name]["valu_issue_cycles"]}
-    return float(tot[0]), float(tot[1]), mix
+    return float(tot[0]), float(tot[1]), float(tot[2]), mix
 
 
 def ubench_line(path, key, value, k):
@@ -330,35 +331,55 @@ def main():
                 traffic = None
         roof = {"kernel": "k_trace8" if wide else "k_trace<NEAREST>", "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches}
         if wide and os.path.exists(ISA_MIX) and os.path.exists(UBENCH_VALU) and cst["sched_iterations"] > 0 and avg_s > 0:
-            n_instr, n_cycles, mix = valu_issue_model(cst)
+            n_instr, n_cycles_meas, n_cycles, mix = valu_issue_model(cst)
             n_instr /= n_launch_c
             n_cycles /= n_launch_c
-            cpi = n_cycles / max(1.0, n_instr)           # issue cycles per instruction of this kernel's mix
+            n_cycles_meas /= n_launch_c
+            cpi = n_cycles / max(1.0, n_instr)           # issue cycles per instruction of this kernel's mix at the NOMINAL class rates (2 / 4 / 8)
+            cpi_meas = n_cycles_meas / max(1.0, n_instr)  # ... with every opcode at the cost the microbenchmark measured (loop overhead included)
             # the model counts every instruction of a region, also sub-branches no lane takes (the hardware skips those): where the
             # committed PMC pass of this binary and workload gives SQ_INSTS_VALU, the count is taken from it and the model gives the mix
-            cal = pmc_valu if pmc_valu else n_instr
+            cal_src = None
+            if pmc_valu:
+                cal = pmc_valu
+            else:
+                # no PMC pass for this workload: the model count divided by the largest model/PMC ratio measured so far (the count errs low)
+                cal = n_instr
+                try:
+                    cj = json.load(open(os.path.join(ROOT, "profiles", "valu_model_calibration.json")))
+                    ratio = max(c["ratio"] for c in cj["calibrations"])
+                    cal = n_instr / ratio
+                    cal_src = "model count / %.4f, the largest model-to-SQ_INSTS_VALU ratio in profiles/valu_model_calibration.json (no PMC pass for this workload)" % ratio
+                except Exception:
+                    cal_src = "model (upper estimate: counts sub-branches no lane takes)"
             ub = ubench_line(UBENCH_VALU, "class", "k_trace8 node step", 5)
             clock = ub["clock_ghz"]
-            peak = N_SIMD * clock                       # G issue cycles per second the chip's SIMDs provide at the sustained clock
+            # peak: every SIMD issuing every clock at the part's highest engine clock.  The clock a kernel sustains depends on
+            # what it does (2.319 GHz under the microbenchmark's pure node-step stream, 2.33-2.35 under k_trace8 itself, whose
+            # waves also wait for memory), so the spec maximum is the one figure no run can exceed
+            peak = N_SIMD * SPEC_CLOCK_GHZ
             achieved = cal * cpi / avg_s / 1e9
             roof.update({
                 "bound": "valu_issue", "unit": "G VALU issue-cycles/s",
                 "achieved": round(achieved, 1), "peak": round(peak, 1), "frac": round(achieved / peak, 4),
-                "frac_at_2.4GHz_spec_clock": round(achieved / (N_SIMD * 2.4), 4),
+                "frac_at_ubench_sustained_clock": round(achieved / (N_SIMD * clock), 4),
+                "frac_with_measured_opcode_costs": round(cal * cpi_meas / avg_s / 1e9 / peak, 4),
                 "definition": "achieved = VALU wave-instructions of one launch x issue cycles per instruction of the kernel's mix / launch duration "
                               "measured in this run (HIP events on the kernel's stream).  Mix: wave-level iteration counts of this run's counting frame x "
-                              "per-region instruction counts of the compiled kernel, each opcode at the LOWEST issue cost measured for it at any occupancy "
-                              "(full-rate %.2f, half-rate %.2f, v_rcp/v_sqrt %.2f cycles per wave64 instruction per SIMD), so the sum is a lower bound of the "
-                              "cycles the stream needs.  peak = %d SIMDs x %.3f GHz, the clock the chip holds under the node step's instruction stream at 5 waves/SIMD"
-                              % (mix["cycles_full_rate"], mix["cycles_half_rate"], mix["cycles_quarter_rate"], N_SIMD, clock),
+                              "per-region instruction counts of the compiled kernel, each opcode at the nominal issue cost of its rate class (2 / 4 / 8 cycles per "
+                              "wave64 instruction per SIMD; the class is the one the microbenchmark measured: full-rate %.2f, half-rate %.2f, v_rcp/v_sqrt %.2f "
+                              "cycles including its loop overhead -- frac_with_measured_opcode_costs prices with those), so the sum is a lower bound of the "
+                              "cycles the stream needs.  peak = %d SIMDs x %.1f GHz (MI355X peak engine clock, MI355X_MICROARCH.md); frac_at_ubench_sustained_clock uses the "
+                              "%.3f GHz the chip holds under the node step's instruction stream alone at 5 waves/SIMD"
+                              % (mix["cycles_full_rate"], mix["cycles_half_rate"], mix["cycles_quarter_rate"], N_SIMD, SPEC_CLOCK_GHZ, clock),
                 "peak_source": "profiles/r02_ubench_valu_issue.jsonl (tools/ubench/valu_issue.hip on MI355X); mix: cudaraytracer_amd/isa_mix_k_trace8.json (tools/isa_mix.py)",
                 "valu_wave_instructions_per_launch": int(cal),
-                "valu_wave_instructions_source": (tsrc + " (SQ_INSTS_VALU)") if pmc_valu else "model (upper estimate: counts sub-branches no lane takes)",
+                "valu_wave_instructions_source": (tsrc + " (SQ_INSTS_VALU)") if pmc_valu else cal_src,
                 "valu_wave_instructions_per_launch_model": int(n_instr),
                 "model_over_pmc": round(n_instr / pmc_valu, 4) if pmc_valu else None,
                 "valu_g_wave_instructions_per_s": round(cal / avg_s / 1e9, 1),
                 "node_step_stream_ceiling_g_wave_instructions_per_s": ub["g_wave_instructions_per_s"],
-                "avg_issue_cycles_per_instruction": round(cpi, 3),
+                "avg_issue_cycles_per_instruction": round(cpi, 3), "avg_issue_cycles_per_instruction_measured_costs": round(cpi_meas, 3),
                 "regions_per_frame": mix["breakdown"],
             })
         else:

@@ -8,7 +8,9 @@ MEASURED by tools/ubench/valu_issue.hip (profiles/r02_ubench_valu_issue.jsonl: c
 SIMD, the lowest over the occupancies measured: ~2.3 for the full-rate opcodes, ~4.1 for the half-rate ones, ~8.1 for
 v_rcp/v_sqrt).
 
-Output (JSON): per region the instruction counts and VALU issue cycles.  bench.py multiplies them by the iteration
+Output (JSON): per region the instruction counts and VALU issue cycles -- with the measured cost of every opcode
+(`valu_issue_cycles`) and with the nominal cost of its rate class (`valu_issue_cycles_nominal`: 2 / 4 / 8 cycles; the
+measurement decides the class, the nominal figure is the floor no stream can go below, which bench.py's roofline uses).  bench.py multiplies them by the iteration
 counts the counting frame reports (node iterations, primitive iterations, refills, finishes) to get the launch's VALU
 instruction count and its issue-cycle demand -- the numerator of the roofline -- and checks the instruction count
 against SQ_INSTS_VALU of the committed PMC pass.
@@ -36,6 +38,9 @@ SIBLING = {
     "v_mul_hi_u32": "v_mul_lo_u32", "v_fmac_f32": "v_fmac_f32", "v_mad_u64_u32": "v_mul_lo_u32",
 }
 CMP = re.compile(r"^v_cmp[x]?_")
+# nominal issue cycles of the three rate classes on the 32-lane SIMD (a wave64 instruction takes 2 passes at full rate); the
+# microbenchmark measures 2.2-2.4 / 4.1 / 8.1 including its own loop overhead.  The class of an opcode comes from its measurement.
+NOMINAL = {"full": 2.0, "half": 4.0, "quarter": 8.0}
 
 
 def load_costs(path, k):
@@ -98,6 +103,7 @@ def main():
                 unknown[op] = unknown.get(op, 0) + 1
             r["valu"] += 1
             r["valu_issue_cycles"] += c
+            r["valu_issue_cycles_nominal"] = r.get("valu_issue_cycles_nominal", 0.0) + NOMINAL[cls]
             r["valu_%s_rate" % cls] += 1
             r["opcodes"][op] = r["opcodes"].get(op, 0) + 1
         elif op.startswith("s_"):
