@@ -43,7 +43,9 @@ class Camera(C.Structure):
 class Params(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("bounces", C.c_int32), ("spp", C.c_int32),
                 ("tile_w", C.c_int32), ("tile_h", C.c_int32), ("rank", C.c_int32), ("nranks", C.c_int32),
-                ("sort_rays", C.c_int32), ("area_samples", C.c_int32), ("use_graph", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("sort_rays", C.c_int32), ("area_samples", C.c_int32), ("use_graph", C.c_int32),
+                ("tile_sub", C.c_int32), ("tile_nsub", C.c_int32), ("grid_div", C.c_int32), ("timing", C.c_int32),
+                ("reserved", C.c_int32 * 1)]
 
 
 class Stats(C.Structure):
@@ -74,10 +76,10 @@ ABI_SYMBOLS = [
     "crt_create", "crt_destroy", "crt_last_error", "crt_params_default", "crt_set_counting",
     "crt_scene_set", "crt_scene_update", "crt_lights_set", "crt_animate_device", "crt_scene_get",
     "crt_bvh_build", "crt_bvh_refit", "crt_bvh_free", "crt_bvh_reference_order", "crt_bvh_dump",
-    "crt_render", "crt_render_device", "crt_set_capture", "crt_get_capture", "crt_get_color",
+    "crt_render", "crt_render_device", "crt_render_submit", "crt_render_wait", "crt_set_capture", "crt_get_capture", "crt_get_color",
     "crt_trace", "crt_trace_shadow", "crt_trace_noalloc", "crt_powf_probe",
     "crt_blob_size", "crt_blob_device_ptr", "crt_blob_import_device",
-    "crt_tile_owner", "crt_tiles_owned", "crt_tiles_pack", "crt_tiles_unpack",
+    "crt_tile_owner", "crt_tiles_owned", "crt_tiles_pack", "crt_tiles_unpack", "crt_tiles_pack_slot", "crt_slot_stream",
     "crt_get_stats", "crt_sync",
     "crt_mgpu_create", "crt_mgpu_destroy", "crt_mgpu_size", "crt_mgpu_uses_rccl", "crt_mgpu_ctx", "crt_mgpu_last_error",
     "crt_mgpu_lights_set", "crt_mgpu_sync_scene", "crt_mgpu_render", "crt_mgpu_render_device", "crt_mgpu_get_times",
@@ -104,6 +106,8 @@ for _name, _args in {
     "crt_bvh_reference_order": [_vp, _vp, _i], "crt_bvh_dump": [_vp, _vp, _vp, _vp, _vp, _i],
     "crt_render": [_vp, C.POINTER(Camera), C.POINTER(Params), _vp],
     "crt_render_device": [_vp, C.POINTER(Camera), C.POINTER(Params), _vp],
+    "crt_render_submit": [_vp, _i, C.POINTER(Camera), C.POINTER(Params), _vp], "crt_render_wait": [_vp, _i],
+    "crt_tiles_pack_slot": [_vp, _i, C.POINTER(Params), _vp, _vp], "crt_slot_stream": [_vp, _i, C.POINTER(_vp)],
     "crt_get_capture": [_vp, _i, _vp, _vp, _i], "crt_get_color": [_vp, _vp, _i],
     "crt_trace": [_vp, _vp, _i, _vp, _vp], "crt_trace_shadow": [_vp, _vp, _i, _vp], "crt_powf_probe": [_vp, _vp, _vp, _i, _vp],
     "crt_trace_noalloc": [_vp, _vp, _i, _vp, _vp],
@@ -373,6 +377,17 @@ class Context:
     def render_device(self, cam, target, params, dev_ptr=None):
         c = self._cam(cam, target)
         self._ck(lib.crt_render_device(self.h, C.byref(c), C.byref(params), dev_ptr))
+
+    def render_submit(self, slot, cam, target, params, dev_ptr=None):
+        """crt_render_submit: queue a frame on frame slot `slot` without waiting; render_wait(slot) completes it."""
+        c = self._cam(cam, target)
+        self._ck(lib.crt_render_submit(self.h, slot, C.byref(c), C.byref(params), dev_ptr))
+
+    def render_wait(self, slot):
+        self._ck(lib.crt_render_wait(self.h, slot))
+
+    def tiles_pack_slot(self, slot, params, dev_bgr, dev_packed):
+        self._ck(lib.crt_tiles_pack_slot(self.h, slot, C.byref(params), dev_bgr, dev_packed))
 
     def capture(self, bounce, npixels):
         ids = np.zeros(npixels, np.int32)

@@ -37,6 +37,42 @@ constexpr int kCtrStride = kCtrFetch0 + 32 * 8 * kFetchStride;
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 }
 
+/* Everything one frame in flight needs besides the scene: see crt_ctx::fs */
+struct FrameSlot {
+    hipStream_t stream = nullptr; bool own_stream = false;
+    bool in_flight = false;          /* submitted, not yet collected by crt_render_wait */
+    hipEvent_t ev_done = nullptr;    /* recorded behind the last launch of every submitted frame (no timing) */
+    hipEvent_t ev_scene = nullptr;   /* slots > 0: the state of the context's stream a frame has to wait for */
+    size_t cap = 0, npix_alloc = 0, nlights_alloc = 0;
+    float4 *rayO[2] = {nullptr, nullptr}, *rayD[2] = {nullptr, nullptr}, *coef[2] = {nullptr, nullptr};
+    uint32_t* pix[2] = {nullptr, nullptr};
+    int32_t* hitSlot = nullptr; float* hitT = nullptr;
+    float4 *rc = nullptr, *contrib = nullptr, *shO = nullptr, *shD = nullptr, *accum = nullptr, *sum = nullptr;
+    uint8_t* shflag = nullptr;
+    /* crt_params.use_graph: the frame's launch sequence captured once and replayed while nothing but the scene's
+     * contents changes */
+    struct GraphKey {
+        crt_camera cam; crt_params p; LightsParam lights;
+        const void* ptrs[20]; uint32_t nnodes, nprims, nmats, depth, mode; int counting, capture, grid, ovf_depth, block; float scene_abs;
+    };
+    GraphKey graph_key{}; hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; bool in_capture = false;
+    uint8_t* d_bgr = nullptr; size_t bgr_cap = 0;
+    int32_t* cap_ids = nullptr; float* cap_ts = nullptr; size_t cap_planes = 0; size_t cap_npix = 0;
+    uint32_t* d_tiles = nullptr; size_t tiles_cap = 0; std::vector<uint32_t> tiles; crt_params tiles_for{}; int64_t owned_pixels = 0;
+    uint32_t* d_ctr = nullptr; size_t ctr_cap = 0;
+    uint32_t* h_ctr = nullptr; size_t h_ctr_cap = 0;             /* pinned: queue sizes of the frame, copied behind its last launch */
+    uint32_t* h_status = nullptr;                                /* pinned: the device status word as the frame left it */
+    uint32_t *d_sortkeys = nullptr, *d_sortperm = nullptr, *d_sorthist = nullptr; size_t sort_cap = 0;     /* shadow queue */
+    uint32_t *d_sortkeys2 = nullptr, *d_sortperm2 = nullptr;                                                 /* reflection queue */
+    bool ev_error = false;             /* a timing event could not be created or recorded since the last submit began */
+    std::vector<hipEvent_t> evpool; size_t evused = 0;
+    std::vector<std::pair<int, int>> evlog;      /* (kind, event index) */
+    /* what crt_render_wait needs to turn the frame's counters into crt_stats */
+    crt_params sub_p{}; int sub_spp = 1; bool sub_counting = false; int sub_grid = 0;
+    int last_w = 0, last_h = 0, last_bounces = 0;
+    bool light_timing = false;       /* crt_params.timing == 1 */
+};
+
 struct crt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -59,46 +95,25 @@ struct crt_ctx {
     uint32_t* d_arrive = nullptr; size_t arrive_cap = 0;
     float scene_abs = 0.f;
 
-    /* frame */
-    size_t cap = 0, npix_alloc = 0, nlights_alloc = 0;
-    float4 *rayO[2] = {nullptr, nullptr}, *rayD[2] = {nullptr, nullptr}, *coef[2] = {nullptr, nullptr};
-    uint32_t* pix[2] = {nullptr, nullptr};
-    int32_t* hitSlot = nullptr; float* hitT = nullptr;
-    float4 *rc = nullptr, *contrib = nullptr, *shO = nullptr, *shD = nullptr, *accum = nullptr, *sum = nullptr;
-    uint8_t* shflag = nullptr;
-    /* crt_params.use_graph: the frame's launch sequence captured once and replayed while nothing but the scene's
-     * contents changes */
-    struct GraphKey {
-        crt_camera cam; crt_params p; LightsParam lights;
-        const void* ptrs[20]; uint32_t nnodes, nprims, nmats, depth, mode; int counting, capture, grid, ovf_depth; float scene_abs;
-    };
-    GraphKey graph_key{}; hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; bool in_capture = false;
-    unsigned char* h_stage = nullptr; size_t stage_cap = 0;     /* pinned staging for crt_render's copy to the caller's buffer */
+    /* frames: every slot owns a stream and a full set of per-frame buffers, so that up to CRT_MAX_FRAME_SLOTS frames
+     * (or tile subsets of one frame) are in flight at once on the read-only scene blob.  Slot 0 runs on the context's own
+     * stream -- the synchronous entry points use it -- the others on streams of their own */
+    FrameSlot fs[CRT_MAX_FRAME_SLOTS];
     float4* d_area_table = nullptr;      /* unit-disk samples of the area lights, uploaded on first use */
-    uint8_t* d_bgr = nullptr; size_t bgr_cap = 0;
-    int32_t* cap_ids = nullptr; float* cap_ts = nullptr; size_t cap_planes = 0; size_t cap_npix = 0;
-    uint32_t* d_tiles = nullptr; size_t tiles_cap = 0; std::vector<uint32_t> tiles; crt_params tiles_for{}; int64_t owned_pixels = 0;
-    std::vector<uint32_t*> tl_ids; std::vector<int> tl_n; crt_params tl_key{};      /* per-rank tile lists for pack/unpack */
-    uint32_t* d_ctr = nullptr; size_t ctr_cap = 0; std::vector<uint32_t> h_ctr;
-    uint32_t *d_sortkeys = nullptr, *d_sortperm = nullptr, *d_sorthist = nullptr; size_t sort_cap = 0;     /* shadow queue */
-    uint32_t *d_sortkeys2 = nullptr, *d_sortperm2 = nullptr;                                                 /* reflection queue */
+    unsigned char* h_stage = nullptr; size_t stage_cap = 0;     /* pinned staging for crt_render's copy to the caller's buffer */
     void* d_lbvh = nullptr; size_t lbvh_cap = 0;                 /* scratch of the device builder */
     Node8* d_lbvh_nodes = nullptr; size_t lbvh_nodes_cap = 0;    /* its output before the blob is laid out */
     uint32_t* d_lbvh_s2s = nullptr; size_t lbvh_s2s_cap = 0;
     void* d_refrank = nullptr; size_t refrank_cap = 0;          /* scratch of the device-side reference-order pass */
     uint32_t* d_refrank_out = nullptr; size_t refrank_out_cap = 0; bool dev_rank_valid = false; uint32_t refrank_levels = 0;
     uint32_t* d_status = nullptr;
-    bool ev_error = false;             /* a timing event could not be created or recorded since the last render call began */
     uint32_t* h_status = nullptr;      /* pinned: crt_trace_noalloc reads the status word without a staging copy */
     void* noalloc_scratch = nullptr;   /* this device's copy of noalloc.hip's scratch array (address looked up once per device) */
     unsigned long long* d_testctr = nullptr;
-    uint32_t* d_ovf = nullptr; size_t ovf_cap = 0; int ovf_depth = 0;
-    int grid_blocks = 1024;
-    int last_w = 0, last_h = 0, last_bounces = 0;
-
-    struct Ev { hipEvent_t e; int kind; };
-    std::vector<hipEvent_t> evpool; size_t evused = 0;
-    std::vector<std::pair<int, int>> evlog;      /* (kind, event index) */
+    uint32_t* d_ovf = nullptr; size_t ovf_cap = 0; size_t ovf_slot_words = 0; int ovf_depth = 0;      /* one area per frame slot */
+    int grid_blocks = 1024;            /* persistent traversal grid, in 256-thread blocks: what is resident at once */
+    int trace_block = 256;             /* threads per block of k_trace8 (CRT_TRACE_BLOCK = 256 / 128 / 64) */
+    std::vector<uint32_t*> tl_ids; std::vector<int> tl_n; crt_params tl_key{};      /* per-rank tile lists for pack/unpack */
     crt_stats stats{};
 };
 
@@ -196,18 +211,21 @@ void layout_blob(BlobHeader& h) {
 
 int size_overflow(crt_ctx* c) {
     /* worst-case stack need: one entry per level, for the 8-wide tree (one 64-bit group entry per
-     * visited node) as for the 2-wide reference topology (one 32-bit link) */
+     * visited node) as for the 2-wide reference topology (one 32-bit link).  Every frame slot gets an area of its own
+     * (their launches overlap); the 8-wide kernel's in-LDS depth depends on its block size */
     const bool wide = c->hdr.mode == CRT_BVH_WIDE;
     const int bound = (int)c->hdr.depth + 2;
-    const int in_lds = wide ? kStackDepth8 : kStackDepth;
+    const int in_lds = wide ? stack_depth8_of(c->trace_block) : kStackDepth;
     c->ovf_depth = bound > in_lds ? bound - in_lds : 0;
-    const size_t need = (size_t)c->grid_blocks * kTraceBlock * (size_t)c->ovf_depth * (wide ? 2 : 1);
+    const size_t per_slot = (size_t)c->grid_blocks * kTraceBlock * (size_t)c->ovf_depth * (wide ? 2 : 1);
+    const size_t need = per_slot * CRT_MAX_FRAME_SLOTS;
     if (need > c->ovf_cap || !c->d_ovf) {
         if (c->d_ovf) HIPCHECK(c, hipFree(c->d_ovf));
         c->d_ovf = nullptr;
         HIPCHECK(c, hipMalloc((void**)&c->d_ovf, (need + 64) * sizeof(uint32_t)));
         c->ovf_cap = need;
     }
+    c->ovf_slot_words = per_slot;
     return CRT_OK;
 }
 
@@ -217,96 +235,135 @@ void scene_abs_from_box(crt_ctx* c) {
     c->scene_abs = m;
 }
 
-/* events come from a pool that only grows; a failure to create or record one is remembered (ev_error) and reported by
- * the call that was timing with it */
-bool reserve_events(crt_ctx* c, size_t k) {          /* the next k calls of next_event() cannot fail afterwards */
-    while (c->evpool.size() < c->evused + k) {
+/* events come from a pool (one per frame slot) that only grows; a failure to create or record one is remembered
+ * (ev_error) and reported by the call that was timing with it */
+bool reserve_events(FrameSlot& f, size_t k) {          /* the next k calls of next_event() cannot fail afterwards */
+    while (f.evpool.size() < f.evused + k) {
         hipEvent_t e = nullptr;
-        if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); c->ev_error = true; return false; }
-        c->evpool.push_back(e);
+        if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); f.ev_error = true; return false; }
+        f.evpool.push_back(e);
     }
     return true;
 }
-hipEvent_t next_event(crt_ctx* c) {
-    if (!reserve_events(c, 1)) return nullptr;
-    return c->evpool[c->evused++];
+hipEvent_t next_event(FrameSlot& f) {
+    if (!reserve_events(f, 1)) return nullptr;
+    return f.evpool[f.evused++];
 }
 enum { EV_START = 0, EV_GEN, EV_TRACE_N, EV_SHADE, EV_TRACE_S, EV_RESOLVE, EV_CONVERT, EV_SORT, EV_TRACE_M };
-void mark(crt_ctx* c, int kind) {
-    if (c->in_capture) return;             /* per-kernel timing is not available for a replayed graph */
-    hipEvent_t e = next_event(c);
+void mark(FrameSlot& f, int kind) {
+    if (f.in_capture) return;             /* per-kernel timing is not available for a replayed graph */
+    if (f.light_timing && kind != EV_START && kind != EV_CONVERT) return;
+    hipEvent_t e = next_event(f);
     if (!e) return;
-    if (hipEventRecord(e, c->stream) != hipSuccess) { c->ev_error = true; c->evused--; return; }
-    c->evlog.emplace_back(kind, (int)c->evused - 1);
+    if (hipEventRecord(e, f.stream) != hipSuccess) { f.ev_error = true; f.evused--; return; }
+    f.evlog.emplace_back(kind, (int)f.evused - 1);
 }
 
-int ensure_tiles(crt_ctx* c, const crt_params* p) {
-    if (c->d_tiles && memcmp(&c->tiles_for, p, sizeof(crt_params)) == 0) return CRT_OK;
+/* a frame slot's stream, events and pinned words; slot 0 borrows the context's stream */
+int ensure_slot(crt_ctx* c, int k) {
+    FrameSlot& f = c->fs[k];
+    if (!f.stream) {
+        if (k == 0) f.stream = c->stream;
+        else { HIPCHECK(c, hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking)); f.own_stream = true; }
+    }
+    if (!f.ev_done) HIPCHECK(c, hipEventCreateWithFlags(&f.ev_done, hipEventDisableTiming));
+    if (k > 0 && !f.ev_scene) HIPCHECK(c, hipEventCreateWithFlags(&f.ev_scene, hipEventDisableTiming));
+    if (!f.h_status) { HIPCHECK(c, hipHostMalloc((void**)&f.h_status, 64, hipHostMallocDefault)); *f.h_status = 0; }
+    return CRT_OK;
+}
+
+/* Frames in flight on the other slots read the scene blob.  Before the context's stream rewrites it in place (animation,
+ * refit, scene update) that stream waits for them -- device-side, the host does not block */
+int order_after_frames(crt_ctx* c) {
+    for (int k = 1; k < CRT_MAX_FRAME_SLOTS; k++)
+        if (c->fs[k].in_flight) HIPCHECK(c, hipStreamWaitEvent(c->stream, c->fs[k].ev_done, 0));
+    return CRT_OK;
+}
+/* ... and before anything is freed or reallocated (build, import, free) the host waits for them */
+int drain_frames(crt_ctx* c) {
+    for (int k = 0; k < CRT_MAX_FRAME_SLOTS; k++)
+        if (c->fs[k].in_flight && c->fs[k].stream) HIPCHECK(c, hipStreamSynchronize(c->fs[k].stream));
+    return CRT_OK;
+}
+
+int ensure_tiles(crt_ctx* c, FrameSlot& f, const crt_params* p) {
+    if (f.d_tiles && memcmp(&f.tiles_for, p, sizeof(crt_params)) == 0) return CRT_OK;
     int nt = 0; int64_t np = 0;
     int rc = crt_tiles_owned(p, &nt, &np, nullptr, 0);
     if (rc) return fail(c, rc, "bad tile parameters");
-    c->tiles.resize(nt);
     std::vector<int32_t> tmp(nt);
     crt_tiles_owned(p, &nt, &np, tmp.data(), nt);
-    for (int i = 0; i < nt; i++) c->tiles[i] = (uint32_t)tmp[i];
-    rc = ensure(c, c->d_tiles, c->tiles_cap, (size_t)nt + 1);
+    /* crt_params.tile_nsub > 1: this call renders every tile_nsub-th tile of the rank's list, starting at tile_sub --
+     * a frame split over several slots (or calls) without touching the rank's tile map, which pack / unpack keep using */
+    const int nsub = p->tile_nsub > 1 ? p->tile_nsub : 1, sub = p->tile_nsub > 1 ? p->tile_sub : 0;
+    f.tiles.clear();
+    np = 0;
+    const int tx = (p->width + p->tile_w - 1) / p->tile_w;
+    for (int i = sub; i < nt; i += nsub) {
+        f.tiles.push_back((uint32_t)tmp[i]);
+        const int x0 = (tmp[i] % tx) * p->tile_w, y0 = (tmp[i] / tx) * p->tile_h;
+        np += (int64_t)(x0 + p->tile_w <= p->width ? p->tile_w : p->width - x0) * (y0 + p->tile_h <= p->height ? p->tile_h : p->height - y0);
+    }
+    rc = ensure(c, f.d_tiles, f.tiles_cap, f.tiles.size() + 1);
     if (rc) return rc;
-    HIPCHECK(c, hipMemcpyAsync(c->d_tiles, c->tiles.data(), nt * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
-    c->tiles_for = *p; c->owned_pixels = np;
+    HIPCHECK(c, hipMemcpyAsync(f.d_tiles, f.tiles.data(), f.tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice, f.stream));
+    HIPCHECK(c, hipStreamSynchronize(f.stream));
+    f.tiles_for = *p; f.owned_pixels = np;
     return CRT_OK;
 }
 
-int ensure_frame(crt_ctx* c, size_t cap, size_t npix, int bounces, int nlights, bool need_sum) {
-    if (cap > c->cap || !c->hitSlot) {
+int ensure_frame(crt_ctx* c, FrameSlot& f, size_t cap, size_t npix, int bounces, int nlights, bool need_sum) {
+    if (cap > f.cap || !f.hitSlot) {
         for (int k = 0; k < 2; k++) {
             int r;
-            if ((r = realloc_exact(c, c->rayO[k], cap))) return r;
-            if ((r = realloc_exact(c, c->rayD[k], cap))) return r;
-            if ((r = realloc_exact(c, c->coef[k], cap))) return r;
-            if ((r = realloc_exact(c, c->pix[k], cap))) return r;
+            if ((r = realloc_exact(c, f.rayO[k], cap))) return r;
+            if ((r = realloc_exact(c, f.rayD[k], cap))) return r;
+            if ((r = realloc_exact(c, f.coef[k], cap))) return r;
+            if ((r = realloc_exact(c, f.pix[k], cap))) return r;
         }
         int r;
-        if ((r = realloc_exact(c, c->hitSlot, cap))) return r;
-        if ((r = realloc_exact(c, c->hitT, cap))) return r;
-        if ((r = realloc_exact(c, c->rc, cap))) return r;
-        c->cap = cap; c->nlights_alloc = 0;
+        if ((r = realloc_exact(c, f.hitSlot, cap))) return r;
+        if ((r = realloc_exact(c, f.hitT, cap))) return r;
+        if ((r = realloc_exact(c, f.rc, cap))) return r;
+        f.cap = cap; f.nlights_alloc = 0;
     }
     const size_t nl = nlights > 0 ? (size_t)nlights : 1;
-    if (nl > c->nlights_alloc) {
+    if (nl > f.nlights_alloc) {
         int r;
-        if ((r = realloc_exact(c, c->contrib, c->cap * nl))) return r;
-        if ((r = realloc_exact(c, c->shflag, c->cap * nl))) return r;
-        if ((r = realloc_exact(c, c->shO, c->cap * nl))) return r;
-        if ((r = realloc_exact(c, c->shD, c->cap * nl))) return r;
-        c->nlights_alloc = nl;
+        if ((r = realloc_exact(c, f.contrib, f.cap * nl))) return r;
+        if ((r = realloc_exact(c, f.shflag, f.cap * nl))) return r;
+        if ((r = realloc_exact(c, f.shO, f.cap * nl))) return r;
+        if ((r = realloc_exact(c, f.shD, f.cap * nl))) return r;
+        f.nlights_alloc = nl;
     }
-    if (npix > c->npix_alloc || !c->accum) {
+    if (npix > f.npix_alloc || !f.accum) {
         int r;
-        if ((r = realloc_exact(c, c->accum, npix))) return r;
-        if (c->sum) { HIPCHECK(c, hipFree(c->sum)); c->sum = nullptr; }
-        c->npix_alloc = npix;
+        if ((r = realloc_exact(c, f.accum, npix))) return r;
+        if (f.sum) { HIPCHECK(c, hipFree(f.sum)); f.sum = nullptr; }
+        f.npix_alloc = npix;
     }
-    if (need_sum && !c->sum) { int r; if ((r = realloc_exact(c, c->sum, c->npix_alloc))) return r; }
-    if (c->capture && ((size_t)bounces > c->cap_planes || npix > c->cap_npix || !c->cap_ids)) {
+    if (need_sum && !f.sum) { int r; if ((r = realloc_exact(c, f.sum, f.npix_alloc))) return r; }
+    if (c->capture && ((size_t)bounces > f.cap_planes || npix > f.cap_npix || !f.cap_ids)) {
         int r;
-        if ((r = realloc_exact(c, c->cap_ids, (size_t)bounces * npix))) return r;
-        if ((r = realloc_exact(c, c->cap_ts, (size_t)bounces * npix))) return r;
-        c->cap_planes = bounces; c->cap_npix = npix;
+        if ((r = realloc_exact(c, f.cap_ids, (size_t)bounces * npix))) return r;
+        if ((r = realloc_exact(c, f.cap_ts, (size_t)bounces * npix))) return r;
+        f.cap_planes = bounces; f.cap_npix = npix;
     }
     return CRT_OK;
+}
+
+/* the status word as a frame left it (copied into the slot's pinned word behind the frame's last launch) */
+int status_error(crt_ctx* c, uint32_t st) {
+    if (!st) return CRT_OK;
+    (void)hipMemsetAsync(c->d_status, 0, 4, c->stream);
+    if (st & 2u) return fail(c, CRT_ERR_BUILD, "wide tree does not fit the compressed node format");
+    return fail(c, CRT_ERR_STATE, "traversal stack overflow: tree deeper than the sized overflow area");
 }
 
 int check_status(crt_ctx* c) {
     uint32_t st = 0;
     HIPCHECK(c, hipMemcpy(&st, c->d_status, 4, hipMemcpyDeviceToHost));
-    if (st) {
-        uint32_t z = 0;
-        hipMemcpy(c->d_status, &z, 4, hipMemcpyHostToDevice);
-        if (st & 2u) return fail(c, CRT_ERR_BUILD, "wide tree does not fit the compressed node format");
-        return fail(c, CRT_ERR_STATE, "traversal stack overflow: tree deeper than the sized overflow area");
-    }
-    return CRT_OK;
+    return status_error(c, st);
 }
 
 /* dumps always carry CRT_BVH_DUMP_WIDTH (8) child entries per node; slots a format does not have are empty */
@@ -352,7 +409,7 @@ int ctx_trace_view(crt_ctx* c, TraceView* v) {
     v->sv = c->built ? view_of(c) : SceneView{};
     v->stream = c->stream; v->device = c->device; v->wide = c->hdr.mode == CRT_BVH_WIDE;
     v->scene_abs = c->scene_abs; v->ovf = c->d_ovf; v->ovf_depth = c->ovf_depth;
-    v->counters = c->d_testctr; v->status = c->d_status; v->h_status = c->h_status; v->grid_blocks = c->grid_blocks;
+    v->counters = c->d_testctr; v->status = c->d_status; v->h_status = c->h_status; v->grid_blocks = c->grid_blocks; v->block = c->trace_block;
     return CRT_OK;
 }
 }  // namespace crt
@@ -377,12 +434,14 @@ crt_ctx* crt_create(int device, int* err) {
     hipMemset(c->d_status, 0, 4);
     hipMemset(c->d_testctr, 0, 32 * sizeof(unsigned long long));
     c->grid_blocks = trace_grid_blocks(device);
+    if (const char* v = getenv("CRT_TRACE_BLOCK")) { const int b = atoi(v); if (trace8_has_block(b)) c->trace_block = b; }
     {   /* crt_trace_noalloc's scratch array: its address on THIS device, looked up while this device is current */
         hipError_t se = hipSuccess;
         c->noalloc_scratch = noalloc_scratch_for_device(device, &se);
         if (!c->noalloc_scratch) { if (err) *err = CRT_ERR_HIP; crt_destroy(c); return nullptr; }
     }
     *c->h_status = 0;
+    if (ensure_slot(c, 0) != CRT_OK) { if (err) *err = CRT_ERR_HIP; crt_destroy(c); return nullptr; }
     if (err) *err = CRT_OK;
     return c;
 }
@@ -390,19 +449,28 @@ crt_ctx* crt_create(int device, int* err) {
 void crt_destroy(crt_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
+    for (FrameSlot& f : c->fs) if (f.stream) hipStreamSynchronize(f.stream);
     hipStreamSynchronize(c->stream);
-    void* ptrs[] = {c->d_blob, c->d_prims, c->d_matid, c->d_arrive, c->rayO[0], c->rayO[1], c->rayD[0], c->rayD[1],
-                    c->coef[0], c->coef[1], c->pix[0], c->pix[1], c->hitSlot, c->hitT, c->rc, c->contrib, c->shO, c->shD,
-                    c->accum, c->sum, c->shflag, c->d_bgr, c->cap_ids, c->cap_ts, c->d_tiles, c->d_ctr, c->d_status,
-                    c->d_testctr, c->d_ovf, c->d_sortkeys, c->d_sortperm, c->d_sorthist, c->d_sortkeys2, c->d_sortperm2,
+    void* ptrs[] = {c->d_blob, c->d_prims, c->d_matid, c->d_arrive, c->d_status, c->d_testctr, c->d_ovf,
                     c->d_lbvh, c->d_lbvh_nodes, c->d_lbvh_s2s, c->d_area_table, c->d_refrank, c->d_refrank_out};
     for (void* p : ptrs) if (p) hipFree(p);
+    for (FrameSlot& f : c->fs) {
+        void* fp[] = {f.rayO[0], f.rayO[1], f.rayD[0], f.rayD[1], f.coef[0], f.coef[1], f.pix[0], f.pix[1], f.hitSlot, f.hitT, f.rc,
+                      f.contrib, f.shO, f.shD, f.accum, f.sum, f.shflag, f.d_bgr, f.cap_ids, f.cap_ts, f.d_tiles, f.d_ctr,
+                      f.d_sortkeys, f.d_sortperm, f.d_sorthist, f.d_sortkeys2, f.d_sortperm2};
+        for (void* p : fp) if (p) hipFree(p);
+        if (f.h_ctr) hipHostFree(f.h_ctr);
+        if (f.h_status) hipHostFree(f.h_status);
+        if (f.graph_exec) hipGraphExecDestroy(f.graph_exec);
+        if (f.graph) hipGraphDestroy(f.graph);
+        for (hipEvent_t e : f.evpool) hipEventDestroy(e);
+        if (f.ev_done) hipEventDestroy(f.ev_done);
+        if (f.ev_scene) hipEventDestroy(f.ev_scene);
+        if (f.own_stream && f.stream) hipStreamDestroy(f.stream);
+    }
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_status) hipHostFree(c->h_status);
-    if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
-    if (c->graph) hipGraphDestroy(c->graph);
     for (uint32_t* q : c->tl_ids) if (q) hipFree(q);
-    for (hipEvent_t e : c->evpool) hipEventDestroy(e);
     hipStreamDestroy(c->stream);
     delete c;
 }
@@ -427,6 +495,7 @@ int crt_scene_set(crt_ctx* c, const crt_prim* prims, int n) {
         if (prims[i].type != 0 && prims[i].type != 1) return fail(c, CRT_ERR_ARG, "crt_scene_set: type must be 0 (sphere) or 1 (triangle)");
     if (!finite_geometry(prims, n)) return fail(c, CRT_ERR_ARG, "crt_scene_set: non-finite coordinate");
     HIPCHECK(c, hipSetDevice(c->device));
+    { const int rc = drain_frames(c); if (rc) return rc; }
     c->prims.assign(prims, prims + n);
     dedupe_materials(c);
     c->built = false; c->have_ref = false; c->imported = false; c->host_stale = false;
@@ -441,6 +510,7 @@ int crt_scene_update(crt_ctx* c, const crt_prim* prims, int n) {
         if (prims[i].type != c->prims[i].type) return fail(c, CRT_ERR_ARG, "crt_scene_update: primitive type changed");
     if (!finite_geometry(prims, n)) return fail(c, CRT_ERR_ARG, "crt_scene_update: non-finite coordinate");
     HIPCHECK(c, hipSetDevice(c->device));
+    { const int rc = order_after_frames(c); if (rc) return rc; }
     c->host_stale = false;
     /* materials keep their ids: only geometry (and normals) move, main.cu:545-573 */
     for (int i = 0; i < n; i++) {
@@ -465,6 +535,7 @@ int crt_animate_device(crt_ctx* c) {
     if (!c) return CRT_ERR_ARG;
     if (c->imported) return fail(c, CRT_ERR_STATE, "crt_animate_device: scene was imported as a blob; set it with crt_scene_set first");
     HIPCHECK(c, hipSetDevice(c->device));
+    { const int rc = order_after_frames(c); if (rc) return rc; }
     const uint32_t n = (uint32_t)c->prims.size();
     AnimParam a;
     animation_matrix(a.m);
@@ -582,6 +653,7 @@ int crt_bvh_build(crt_ctx* c, int mode) {
     if (mode != CRT_BVH_WIDE && mode != CRT_BVH_REFERENCE && mode != CRT_BVH_WIDE_DEVICE) return fail(c, CRT_ERR_ARG, "crt_bvh_build: unknown mode");
     if (c->imported) return fail(c, CRT_ERR_STATE, "crt_bvh_build: scene was imported as a blob");
     HIPCHECK(c, hipSetDevice(c->device));
+    { const int rc = drain_frames(c); if (rc) return rc; }      /* the blob may move: no frame may still be reading it */
     if (mode == CRT_BVH_WIDE_DEVICE) {
         if (!c->prims.empty()) return build_on_device(c);
         mode = CRT_BVH_WIDE;                 /* nothing to sort: the host path writes the empty root */
@@ -662,9 +734,11 @@ int crt_bvh_refit(crt_ctx* c, int grow_only) {
     if (!c->built) return fail(c, CRT_ERR_STATE, "crt_bvh_refit: no BVH (call crt_bvh_build)");
     HIPCHECK(c, hipSetDevice(c->device));
     char* b = (char*)c->d_blob;
-    if (!reserve_events(c, 2)) return fail(c, CRT_ERR_HIP, "crt_bvh_refit: hipEventCreate failed");
-    hipEvent_t e0 = next_event(c), e1 = next_event(c);
-    c->evused -= 2;
+    { const int rc = order_after_frames(c); if (rc) return rc; }
+    FrameSlot& f0 = c->fs[0];
+    if (!reserve_events(f0, 2)) return fail(c, CRT_ERR_HIP, "crt_bvh_refit: hipEventCreate failed");
+    hipEvent_t e0 = next_event(f0), e1 = next_event(f0);
+    f0.evused -= 2;
     HIPCHECK(c, hipEventRecord(e0, c->stream));
     if (c->hdr.mode == CRT_BVH_WIDE) {
         launch_refit8((Node8*)(b + c->hdr.off_nodes), c->hdr.nnodes, (const Geom*)(b + c->hdr.off_geom), c->d_arrive,
@@ -686,6 +760,7 @@ int crt_bvh_refit(crt_ctx* c, int grow_only) {
 int crt_bvh_free(crt_ctx* c) {
     if (!c) return CRT_ERR_ARG;
     HIPCHECK(c, hipSetDevice(c->device));
+    { const int rc = drain_frames(c); if (rc) return rc; }
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     if (c->d_blob) { HIPCHECK(c, hipFree(c->d_blob)); c->d_blob = nullptr; }
     c->blob_cap = c->blob_bytes = 0; c->built = false; c->imported = false;
@@ -779,16 +854,31 @@ static int fill_frame_params(crt_ctx* c, const crt_camera* cam, const crt_params
     return CRT_OK;
 }
 
-int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, void* dev_bgr) {
+/* One frame enqueued on a slot's stream: gen_primary -> [trace -> shade -> trace(shadow + next bounce) -> resolve] x bounces
+ * -> convert, then the frame's queue sizes and the status word into pinned host words, then the slot's done event.
+ * Nothing here waits for the device (first use of a slot or of a frame size allocates, which does). */
+int crt_render_submit(crt_ctx* c, int slot, const crt_camera* cam, const crt_params* p, void* dev_bgr) {
     if (!c) return CRT_ERR_ARG;
+    if (slot < 0 || slot >= CRT_MAX_FRAME_SLOTS) return fail(c, CRT_ERR_ARG, "crt_render_submit: slot must be 0..CRT_MAX_FRAME_SLOTS-1");
     if (!c->built) return fail(c, CRT_ERR_STATE, "render: no BVH (call crt_scene_set + crt_bvh_build, or import a blob)");
+    FrameSlot& f = c->fs[slot];
+    if (f.in_flight) return fail(c, CRT_ERR_STATE, "crt_render_submit: the slot still holds a frame (crt_render_wait collects it)");
     HIPCHECK(c, hipSetDevice(c->device));
     FrameParams fp;
     int rc = fill_frame_params(c, cam, p, fp);
     if (rc) return rc;
-    rc = ensure_tiles(c, p);
+    if (p->tile_nsub > 1 && (p->tile_sub < 0 || p->tile_sub >= p->tile_nsub)) return fail(c, CRT_ERR_ARG, "render: tile_sub must be 0..tile_nsub-1");
+    if (p->grid_div < 0 || p->grid_div > 64) return fail(c, CRT_ERR_ARG, "render: grid_div must be 0..64");
+    if (c->counting || p->use_graph) {
+        /* the test counters are one set per context, and a captured graph is replayed on the stream it was captured on */
+        if (slot != 0) return fail(c, CRT_ERR_ARG, "render: counting and graph replay run on slot 0 only");
+        if (c->counting) for (int k = 1; k < CRT_MAX_FRAME_SLOTS; k++)
+            if (c->fs[k].in_flight) return fail(c, CRT_ERR_STATE, "render: counting needs the other slots idle");
+    }
+    if ((rc = ensure_slot(c, slot))) return rc;
+    rc = ensure_tiles(c, f, p);
     if (rc) return rc;
-    fp.ntiles_owned = (int)c->tiles.size();
+    fp.ntiles_owned = (int)f.tiles.size();
     const size_t cap = (size_t)fp.ntiles_owned * p->tile_w * p->tile_h;
     const size_t npix = (size_t)p->width * p->height;
     const int spp = fp.spp_n * fp.spp_n;
@@ -815,64 +905,74 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
             HIPCHECK(c, hipMemcpy(c->d_area_table, t4.data(), sizeof(float4) * kAreaTable, hipMemcpyHostToDevice));
         }
     }
-    rc = ensure_frame(c, cap > 0 ? cap : 64, npix, p->bounces, lights.nslots, spp > 1);
+    rc = ensure_frame(c, f, cap > 0 ? cap : 64, npix, p->bounces, lights.nslots, spp > 1);
     if (rc) return rc;
     if (!dev_bgr) {
-        rc = ensure(c, c->d_bgr, c->bgr_cap, npix * 3);
+        rc = ensure(c, f.d_bgr, f.bgr_cap, npix * 3);
         if (rc) return rc;
-        dev_bgr = c->d_bgr;
+        dev_bgr = f.d_bgr;
     }
     if (p->sort_rays) {
-        const size_t need = c->cap * (size_t)(lights.nslots > 1 ? lights.nslots : 1);
-        if (need > c->sort_cap || !c->d_sortkeys) {
-            if ((rc = realloc_exact(c, c->d_sortkeys, need))) return rc;
-            if ((rc = realloc_exact(c, c->d_sortperm, need))) return rc;
-            if ((rc = realloc_exact(c, c->d_sortkeys2, c->cap))) return rc;
-            if ((rc = realloc_exact(c, c->d_sortperm2, c->cap))) return rc;
-            if (!c->d_sorthist && (rc = realloc_exact(c, c->d_sorthist, (size_t)kSortBins + 1))) return rc;
-            c->sort_cap = need;
+        const size_t need = f.cap * (size_t)(lights.nslots > 1 ? lights.nslots : 1);
+        if (need > f.sort_cap || !f.d_sortkeys) {
+            if ((rc = realloc_exact(c, f.d_sortkeys, need))) return rc;
+            if ((rc = realloc_exact(c, f.d_sortperm, need))) return rc;
+            if ((rc = realloc_exact(c, f.d_sortkeys2, f.cap))) return rc;
+            if ((rc = realloc_exact(c, f.d_sortperm2, f.cap))) return rc;
+            if (!f.d_sorthist && (rc = realloc_exact(c, f.d_sorthist, (size_t)kSortBins + 1))) return rc;
+            f.sort_cap = need;
         }
     }
-    rc = ensure(c, c->d_ctr, c->ctr_cap, (size_t)spp * kCtrStride);
+    rc = ensure(c, f.d_ctr, f.ctr_cap, (size_t)spp * kCtrStride);
     if (rc) return rc;
-    c->h_ctr.assign((size_t)spp * kCtrStride, 0);
-    HIPCHECK(c, hipMemsetAsync(c->d_ctr, 0, (size_t)spp * kCtrStride * 4, c->stream));
-    static const bool tail_probe = getenv("CRT_TAIL_PROBE") != nullptr;
-    if (c->counting || tail_probe) HIPCHECK(c, hipMemsetAsync(c->d_testctr, 0, 32 * sizeof(unsigned long long), c->stream));
-    if (c->capture) {
-        HIPCHECK(c, hipMemsetD32Async((hipDeviceptr_t)c->cap_ids, -9, (size_t)p->bounces * npix, c->stream));
-        HIPCHECK(c, hipMemsetD32Async((hipDeviceptr_t)c->cap_ts, 0, (size_t)p->bounces * npix, c->stream));
+    if ((size_t)spp * kCtrFetch0 > f.h_ctr_cap || !f.h_ctr) {
+        if (f.h_ctr) { HIPCHECK(c, hipHostFree(f.h_ctr)); f.h_ctr = nullptr; f.h_ctr_cap = 0; }
+        HIPCHECK(c, hipHostMalloc((void**)&f.h_ctr, (size_t)spp * kCtrFetch0 * 4, hipHostMallocDefault));
+        f.h_ctr_cap = (size_t)spp * kCtrFetch0;
     }
-    c->evused = 0; c->evlog.clear(); c->ev_error = false;
+    if (slot > 0) {      /* behind whatever the context's stream has queued for the scene (animation, refit, upload) */
+        HIPCHECK(c, hipEventRecord(f.ev_scene, c->stream));
+        HIPCHECK(c, hipStreamWaitEvent(f.stream, f.ev_scene, 0));
+    }
+    HIPCHECK(c, hipMemsetAsync(f.d_ctr, 0, (size_t)spp * kCtrStride * 4, f.stream));
+    static const bool tail_probe = getenv("CRT_TAIL_PROBE") != nullptr;
+    if (c->counting || tail_probe) HIPCHECK(c, hipMemsetAsync(c->d_testctr, 0, 32 * sizeof(unsigned long long), f.stream));
+    if (c->capture) {
+        HIPCHECK(c, hipMemsetD32Async((hipDeviceptr_t)f.cap_ids, -9, (size_t)p->bounces * npix, f.stream));
+        HIPCHECK(c, hipMemsetD32Async((hipDeviceptr_t)f.cap_ts, 0, (size_t)p->bounces * npix, f.stream));
+    }
+    f.evused = 0; f.evlog.clear(); f.ev_error = false; f.light_timing = p->timing == 1;
     const SceneView sv = view_of(c);
     /* the slab-test pad scales with the scene's extent, a kernel argument: a replayed graph keeps the value it was
      * captured with, so graph mode rounds it up to a power of two (a larger pad is as conservative) and re-captures
      * only when an animated scene outgrows it */
     float sabs = c->scene_abs;
-    const int gb = c->grid_blocks;
+    int gb = c->grid_blocks / (p->grid_div > 1 ? p->grid_div : 1);
+    if (gb < 1) gb = 1;
+    uint32_t* const ovf = c->d_ovf + (size_t)slot * c->ovf_slot_words;
     if (p->use_graph) { int e = 0; (void)frexpf(sabs > 0.f ? sabs : 1.f, &e); sabs = ldexpf(1.0f, e); }
     auto enqueue = [&]() {
     for (int s = 0; s < spp; s++) {
-        uint32_t* ctr = c->d_ctr + (size_t)s * kCtrStride;
+        uint32_t* ctr = f.d_ctr + (size_t)s * kCtrStride;
         fp.sample = s;
         int cur = 0;
         FrameBuffers fb{};
-        fb.hitSlot = c->hitSlot; fb.hitT = c->hitT; fb.rc = c->rc; fb.contrib = c->contrib; fb.shflag = c->shflag;
-        fb.shO = c->shO; fb.shD = c->shD; fb.area_table = c->d_area_table; fb.accum = c->accum; fb.cap_ids = c->cap_ids; fb.cap_ts = c->cap_ts;
-        fb.cap = (uint32_t)c->cap; fb.cap_stride = (uint32_t)npix; fb.tile_ids = c->d_tiles;
+        fb.hitSlot = f.hitSlot; fb.hitT = f.hitT; fb.rc = f.rc; fb.contrib = f.contrib; fb.shflag = f.shflag;
+        fb.shO = f.shO; fb.shD = f.shD; fb.area_table = c->d_area_table; fb.accum = f.accum; fb.cap_ids = f.cap_ids; fb.cap_ts = f.cap_ts;
+        fb.cap = (uint32_t)f.cap; fb.cap_stride = (uint32_t)npix; fb.tile_ids = f.d_tiles;
         auto bind = [&](int k) {
-            fb.rayO = c->rayO[k]; fb.rayD = c->rayD[k]; fb.coef = c->coef[k]; fb.pix = c->pix[k];
-            fb.nrayO = c->rayO[k ^ 1]; fb.nrayD = c->rayD[k ^ 1]; fb.ncoef = c->coef[k ^ 1]; fb.npix = c->pix[k ^ 1];
+            fb.rayO = f.rayO[k]; fb.rayD = f.rayD[k]; fb.coef = f.coef[k]; fb.pix = f.pix[k];
+            fb.nrayO = f.rayO[k ^ 1]; fb.nrayD = f.rayD[k ^ 1]; fb.ncoef = f.coef[k ^ 1]; fb.npix = f.pix[k ^ 1];
         };
         bind(cur);
-        launch_gen_primary(fp, fb, ctr + 0, c->stream);
-        mark(c, EV_GEN);
+        launch_gen_primary(fp, fb, ctr + 0, f.stream);
+        mark(f, EV_GEN);
         const float* d_root_box = (const float*)((const char*)c->d_blob + offsetof(BlobHeader, root_box));
         const bool wide = c->hdr.mode == CRT_BVH_WIDE;
         auto common = [&](TraceArgs& t, int launch) {
             t.sv = sv; t.next = ctr + kCtrFetch0 + launch * 8 * kFetchStride;
-            t.hitSlot = c->hitSlot; t.hitT = c->hitT; t.shflag = c->shflag; t.scene_abs = sabs;
-            t.ovf = c->d_ovf; t.ovf_depth = c->ovf_depth; t.counters = c->d_testctr; t.status = c->d_status;
+            t.hitSlot = f.hitSlot; t.hitT = f.hitT; t.shflag = f.shflag; t.scene_abs = sabs;
+            t.ovf = ovf; t.ovf_depth = c->ovf_depth; t.counters = c->d_testctr; t.status = c->d_status; t.block = c->trace_block;
         };
         for (int b = 0; b < p->bounces; b++) {
             fp.bounce = b;
@@ -883,11 +983,11 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
                 TraceArgs ta{};
                 common(ta, 2 * b);
                 ta.rayO = fb.rayO; ta.rayD = fb.rayD; ta.count = ctr + b;
-                launch_trace(ta, TRACE_NEAREST, c->counting, wide, gb, c->stream);
-                mark(c, EV_TRACE_N);
+                launch_trace(ta, TRACE_NEAREST, c->counting, wide, gb, f.stream);
+                mark(f, EV_TRACE_N);
             }
-            launch_shade(fp, fb, sv, lights, ctr + b, ctr + b + 1, ctr + 16 + b, c->stream);
-            mark(c, EV_SHADE);
+            launch_shade(fp, fb, sv, lights, ctr + b, ctr + b + 1, ctr + 16 + b, f.stream);
+            mark(f, EV_SHADE);
             if (wide) {
                 /* ONE launch for the shadow rays of this bounce and the nearest-hit rays of the next: they are
                  * independent, and every persistent launch ends in a ~0.25 ms tail of its longest rays */
@@ -895,99 +995,118 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
                 common(tm, 2 * b + 1);
                 const bool has_sh = c->lights.n > 0, has_nx = b + 1 < p->bounces;
                 if (has_sh) {
-                    tm.shO = c->shO; tm.shD = c->shD; tm.shcount = ctr + 16 + b;
+                    tm.shO = f.shO; tm.shD = f.shD; tm.shcount = ctr + 16 + b;
                     if (p->sort_rays) {
-                        launch_sort_rays(c->shO, ctr + 16 + b, (uint32_t)(c->cap * (size_t)lights.nslots), d_root_box, c->d_sortkeys, c->d_sorthist,
-                                         c->d_sortperm, c->stream);
-                        tm.shperm = c->d_sortperm;
-                        mark(c, EV_SORT);
+                        launch_sort_rays(f.shO, ctr + 16 + b, (uint32_t)(f.cap * (size_t)lights.nslots), d_root_box, f.d_sortkeys, f.d_sorthist,
+                                         f.d_sortperm, f.stream);
+                        tm.shperm = f.d_sortperm;
+                        mark(f, EV_SORT);
                     }
                 }
                 if (has_nx) {
                     tm.rayO = fb.nrayO; tm.rayD = fb.nrayD; tm.count = ctr + b + 1;
                     if (p->sort_rays) {      /* reflection rays: visit them by origin cell (primary rays are coherent already) */
-                        launch_sort_rays(fb.nrayO, ctr + b + 1, (uint32_t)c->cap, d_root_box, c->d_sortkeys2, c->d_sorthist, c->d_sortperm2, c->stream);
-                        tm.perm = c->d_sortperm2;
-                        mark(c, EV_SORT);
+                        launch_sort_rays(fb.nrayO, ctr + b + 1, (uint32_t)f.cap, d_root_box, f.d_sortkeys2, f.d_sorthist, f.d_sortperm2, f.stream);
+                        tm.perm = f.d_sortperm2;
+                        mark(f, EV_SORT);
                     }
                 }
                 if (has_sh || has_nx) {
-                    launch_trace(tm, TRACE_NEAREST, c->counting, true, gb, c->stream);
-                    mark(c, has_sh && has_nx ? EV_TRACE_M : (has_sh ? EV_TRACE_S : EV_TRACE_N));
+                    launch_trace(tm, TRACE_NEAREST, c->counting, true, gb, f.stream);
+                    mark(f, has_sh && has_nx ? EV_TRACE_M : (has_sh ? EV_TRACE_S : EV_TRACE_N));
                 }
             } else if (c->lights.n > 0) {
                 TraceArgs ts{};
                 common(ts, 2 * b + 1);
-                ts.rayO = c->shO; ts.rayD = c->shD; ts.count = ctr + 16 + b;
+                ts.rayO = f.shO; ts.rayD = f.shD; ts.count = ctr + 16 + b;
                 ts.hitSlot = nullptr; ts.hitT = nullptr; ts.counters = c->d_testctr + 16;
-                launch_trace(ts, TRACE_SHADOW, c->counting, false, gb, c->stream);
-                mark(c, EV_TRACE_S);
+                launch_trace(ts, TRACE_SHADOW, c->counting, false, gb, f.stream);
+                mark(f, EV_TRACE_S);
             }
-            launch_resolve(fb, lights, ctr + b, c->stream);
-            mark(c, EV_RESOLVE);
+            launch_resolve(fb, lights, ctr + b, f.stream);
+            mark(f, EV_RESOLVE);
             cur ^= 1;
         }
-        if (spp > 1) launch_spp_accumulate(fp, fb, c->sum, c->stream);
+        if (spp > 1) launch_spp_accumulate(fp, fb, f.sum, f.stream);
     }
     {
         FrameBuffers fb{};
-        fb.accum = c->accum; fb.tile_ids = c->d_tiles;
-        launch_convert(fp, fb, spp > 1 ? c->sum : nullptr, (uint8_t*)dev_bgr, c->stream);
-        mark(c, EV_CONVERT);
+        fb.accum = f.accum; fb.tile_ids = f.d_tiles;
+        launch_convert(fp, fb, spp > 1 ? f.sum : nullptr, (uint8_t*)dev_bgr, f.stream);
+        mark(f, EV_CONVERT);
     }
     };
     if (!p->use_graph) {
-        mark(c, EV_START);
+        mark(f, EV_START);
         enqueue();
     } else {
-        crt_ctx::GraphKey key{};
+        FrameSlot::GraphKey key{};
         key.cam = *cam; key.p = *p; key.lights = lights;
         /* everything a captured launch bakes in: every buffer (size_overflow() may move d_ovf and change ovf_depth on any
          * rebuild or import that leaves the blob's address and counts as they were), every header field the offsets derive from */
-        const void* ptrs[20] = {c->d_blob, c->rayO[0], c->rayO[1], c->hitSlot, c->rc, c->contrib, c->shO, c->accum, c->d_ctr, dev_bgr,
-                                c->d_tiles, c->cap_ids, c->d_ovf, c->d_sortkeys, c->d_sortperm, c->d_sortkeys2, c->d_sortperm2, c->d_sorthist,
-                                c->d_area_table, c->sum};
+        const void* ptrs[20] = {c->d_blob, f.rayO[0], f.rayO[1], f.hitSlot, f.rc, f.contrib, f.shO, f.accum, f.d_ctr, dev_bgr,
+                                f.d_tiles, f.cap_ids, c->d_ovf, f.d_sortkeys, f.d_sortperm, f.d_sortkeys2, f.d_sortperm2, f.d_sorthist,
+                                c->d_area_table, f.sum};
         memcpy(key.ptrs, ptrs, sizeof ptrs);
         key.nnodes = c->hdr.nnodes; key.nprims = c->hdr.nprims; key.nmats = c->hdr.nmats; key.depth = c->hdr.depth; key.mode = c->hdr.mode;
-        key.counting = c->counting; key.capture = c->capture; key.grid = c->grid_blocks; key.ovf_depth = c->ovf_depth; key.scene_abs = sabs;
-        if (!c->graph_exec || memcmp(&key, &c->graph_key, sizeof key) != 0) {
-            if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
-            if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
-            HIPCHECK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
-            c->in_capture = true;
+        key.counting = c->counting; key.capture = c->capture; key.grid = gb; key.ovf_depth = c->ovf_depth; key.block = c->trace_block; key.scene_abs = sabs;
+        if (!f.graph_exec || memcmp(&key, &f.graph_key, sizeof key) != 0) {
+            if (f.graph_exec) { hipGraphExecDestroy(f.graph_exec); f.graph_exec = nullptr; }
+            if (f.graph) { hipGraphDestroy(f.graph); f.graph = nullptr; }
+            HIPCHECK(c, hipStreamBeginCapture(f.stream, hipStreamCaptureModeRelaxed));
+            f.in_capture = true;
             enqueue();
-            c->in_capture = false;
-            HIPCHECK(c, hipStreamEndCapture(c->stream, &c->graph));
-            HIPCHECK(c, hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
-            memcpy(&c->graph_key, &key, sizeof key);
+            f.in_capture = false;
+            HIPCHECK(c, hipStreamEndCapture(f.stream, &f.graph));
+            HIPCHECK(c, hipGraphInstantiate(&f.graph_exec, f.graph, nullptr, nullptr, 0));
+            memcpy(&f.graph_key, &key, sizeof key);
         }
-        mark(c, EV_START);
-        HIPCHECK(c, hipGraphLaunch(c->graph_exec, c->stream));
-        mark(c, EV_CONVERT);
+        mark(f, EV_START);
+        HIPCHECK(c, hipGraphLaunch(f.graph_exec, f.stream));
+        mark(f, EV_CONVERT);
     }
     HIPCHECK(c, hipGetLastError());
     for (int s = 0; s < spp; s++)      /* queue sizes only; the fetch counters stay on the device */
-        HIPCHECK(c, hipMemcpyAsync(&c->h_ctr[(size_t)s * kCtrStride], c->d_ctr + (size_t)s * kCtrStride, kCtrFetch0 * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
-    rc = check_status(c);
+        HIPCHECK(c, hipMemcpyAsync(f.h_ctr + (size_t)s * kCtrFetch0, f.d_ctr + (size_t)s * kCtrStride, kCtrFetch0 * 4, hipMemcpyDeviceToHost, f.stream));
+    HIPCHECK(c, hipMemcpyAsync(f.h_status, c->d_status, 4, hipMemcpyDeviceToHost, f.stream));
+    HIPCHECK(c, hipEventRecord(f.ev_done, f.stream));
+    f.in_flight = true;
+    f.sub_p = *p; f.sub_spp = spp; f.sub_counting = c->counting; f.sub_grid = gb;
+    return CRT_OK;
+}
+
+/* Completes the frame submitted on `slot`: waits for its done event, checks the status word, and turns the frame's
+ * counters and events into crt_stats (crt_get_stats then describes this frame). */
+int crt_render_wait(crt_ctx* c, int slot) {
+    if (!c) return CRT_ERR_ARG;
+    if (slot < 0 || slot >= CRT_MAX_FRAME_SLOTS) return fail(c, CRT_ERR_ARG, "crt_render_wait: slot must be 0..CRT_MAX_FRAME_SLOTS-1");
+    FrameSlot& f = c->fs[slot];
+    if (!f.in_flight) return fail(c, CRT_ERR_STATE, "crt_render_wait: no frame was submitted on this slot");
+    HIPCHECK(c, hipSetDevice(c->device));
+    f.in_flight = false;
+    HIPCHECK(c, hipEventSynchronize(f.ev_done));
+    const crt_params* p = &f.sub_p;
+    const int spp = f.sub_spp;
+    int rc = status_error(c, *f.h_status);
+    *f.h_status = 0;
     if (rc) return rc;
-    if (c->ev_error || c->evlog.size() < 2) return fail(c, CRT_ERR_HIP, "render: a timing event could not be created or recorded (the frame itself is complete)");
+    if (f.ev_error || f.evlog.size() < 2) return fail(c, CRT_ERR_HIP, "render: a timing event could not be created or recorded (the frame itself is complete)");
 
     crt_stats& st = c->stats;
     st.rays_primary = st.rays_shadow = st.rays_reflect = 0;
     for (int s = 0; s < spp; s++) {
-        const uint32_t* h = &c->h_ctr[(size_t)s * kCtrStride];
+        const uint32_t* h = f.h_ctr + (size_t)s * kCtrFetch0;
         (void)h[0];                       /* queue length including holes of clipped tiles */
-        st.rays_primary += (uint64_t)c->owned_pixels;
+        st.rays_primary += (uint64_t)f.owned_pixels;
         for (int b = 1; b < p->bounces; b++) st.rays_reflect += h[b];
         for (int b = 0; b < p->bounces; b++) st.rays_shadow += h[16 + b];
     }
     st.ms_trace = st.ms_shade = st.ms_other = st.ms_trace_nearest = st.ms_trace_shadow = st.ms_trace_mixed = 0;
     st.launches_trace_nearest = st.launches_trace_shadow = st.launches_trace_mixed = 0;
-    for (size_t i = 1; i < c->evlog.size(); i++) {
+    for (size_t i = 1; i < f.evlog.size(); i++) {
         float ms = 0;
-        hipEventElapsedTime(&ms, c->evpool[c->evlog[i - 1].second], c->evpool[c->evlog[i].second]);
-        switch (c->evlog[i].first) {
+        hipEventElapsedTime(&ms, f.evpool[f.evlog[i - 1].second], f.evpool[f.evlog[i].second]);
+        switch (f.evlog[i].first) {
             case EV_TRACE_N: st.ms_trace += ms; st.ms_trace_nearest += ms; st.launches_trace_nearest++; break;
             case EV_TRACE_S: st.ms_trace += ms; st.ms_trace_shadow += ms; st.launches_trace_shadow++; break;
             case EV_TRACE_M: st.ms_trace += ms; st.ms_trace_mixed += ms; st.launches_trace_mixed++; break;
@@ -996,16 +1115,19 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
         }
     }
     float tot = 0;
-    hipEventElapsedTime(&tot, c->evpool[c->evlog.front().second], c->evpool[c->evlog.back().second]);
+    hipEventElapsedTime(&tot, f.evpool[f.evlog.front().second], f.evpool[f.evlog.back().second]);
     st.ms_total = tot;
-    if (tail_probe && !c->counting) {
+    if (f.light_timing) { st.ms_other = 0; }          /* crt_params.timing = 1: start and end only */
+    static const bool tail_probe = getenv("CRT_TAIL_PROBE") != nullptr;
+    const int waves_per_launch = f.sub_grid * (kTraceBlock / 64);
+    if (tail_probe && !f.sub_counting) {
         unsigned long long t[32];
         HIPCHECK(c, hipMemcpy(t, c->d_testctr, sizeof t, hipMemcpyDeviceToHost));
         const int launches = st.launches_trace_nearest + st.launches_trace_shadow + st.launches_trace_mixed;
         fprintf(stderr, "[crt tail] %d launches, %.3f ms of traversal: wave tails (queue dry -> wave done) longest %.0f, mean %.0f shader clocks (s_memtime; / ~2320 for us)\n",
-                launches, st.ms_trace, (double)t[30], launches ? (double)t[31] / ((double)c->grid_blocks * (kTraceBlock / 64) * launches) : 0.0);
+                launches, st.ms_trace, (double)t[30], launches ? (double)t[31] / ((double)waves_per_launch * launches) : 0.0);
     }
-    if (c->counting) {
+    if (f.sub_counting) {
         unsigned long long t[32];
         HIPCHECK(c, hipMemcpy(t, c->d_testctr, sizeof t, hipMemcpyDeviceToHost));
         if (getenv("CRT_DEBUG_SCHED"))      /* wave scheduling statistics of k_trace8 */
@@ -1023,16 +1145,22 @@ int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, vo
         st.sched_active_lanes = t[12]; st.visits_no_child_hit = t[13]; st.visits_no_child_hit_tlimit = t[28]; st.boxes_rejected_by_tlimit = t[29];
         st.sched_iterations = t[20]; st.sched_refill_iterations = t[21]; st.sched_finish_iterations = t[22]; st.sched_setup_iterations = t[23];
         st.sched_pop_iterations = t[24]; st.sched_decode_iterations = t[25]; st.sched_hit_iterations = t[26];
-        st.trace_waves = (uint64_t)(st.launches_trace_nearest + st.launches_trace_shadow + st.launches_trace_mixed) * (uint64_t)c->grid_blocks * (kTraceBlock / 64);
+        st.trace_waves = (uint64_t)(st.launches_trace_nearest + st.launches_trace_shadow + st.launches_trace_mixed) * (uint64_t)waves_per_launch;
     }
-    c->last_w = p->width; c->last_h = p->height; c->last_bounces = p->bounces;
+    f.last_w = p->width; f.last_h = p->height; f.last_bounces = p->bounces;
     return CRT_OK;
+}
+
+int crt_render_device(crt_ctx* c, const crt_camera* cam, const crt_params* p, void* dev_bgr) {
+    const int rc = crt_render_submit(c, 0, cam, p, dev_bgr);
+    return rc ? rc : crt_render_wait(c, 0);
 }
 
 int crt_render(crt_ctx* c, const crt_camera* cam, const crt_params* p, unsigned char* bgr_out_host) {
     if (!c || !bgr_out_host) return fail(c, CRT_ERR_ARG, "crt_render: null output buffer");
     int rc = crt_render_device(c, cam, p, nullptr);
     if (rc) return rc;
+    FrameSlot& f0 = c->fs[0];
     const size_t bytes = (size_t)p->width * p->height * 3;
     /* The caller's buffer is ordinary pageable memory (the reference mallocs it, main.cu:512): a plain hipMemcpy into it
      * runs at ~7 GB/s.  Frames of a few MB and more go through a pinned staging buffer instead: the device copies it in
@@ -1040,7 +1168,7 @@ int crt_render(crt_ctx* c, const crt_camera* cam, const crt_params* p, unsigned 
     constexpr size_t kStageMin = 2u << 20;
     constexpr int kChunks = 8, kThreads = 4;
     if (bytes < kStageMin) {
-        HIPCHECK(c, hipMemcpy(bgr_out_host, c->d_bgr, bytes, hipMemcpyDeviceToHost));
+        HIPCHECK(c, hipMemcpy(bgr_out_host, f0.d_bgr, bytes, hipMemcpyDeviceToHost));
         return CRT_OK;
     }
     if (bytes > c->stage_cap || !c->h_stage) {
@@ -1048,7 +1176,7 @@ int crt_render(crt_ctx* c, const crt_camera* cam, const crt_params* p, unsigned 
         if (hipHostMalloc((void**)&c->h_stage, bytes, hipHostMallocDefault) != hipSuccess) {
             (void)hipGetLastError();
             c->h_stage = nullptr;                    /* no pinned memory to be had: the plain copy still works */
-            HIPCHECK(c, hipMemcpy(bgr_out_host, c->d_bgr, bytes, hipMemcpyDeviceToHost));
+            HIPCHECK(c, hipMemcpy(bgr_out_host, f0.d_bgr, bytes, hipMemcpyDeviceToHost));
             return CRT_OK;
         }
         c->stage_cap = bytes;
@@ -1056,14 +1184,14 @@ int crt_render(crt_ctx* c, const crt_camera* cam, const crt_params* p, unsigned 
     const size_t chunk = ((bytes + kChunks - 1) / kChunks + 4095) & ~(size_t)4095;
     hipEvent_t ev[kChunks];
     int nchunks = 0;
-    if (!reserve_events(c, (size_t)kChunks)) return fail(c, CRT_ERR_HIP, "crt_render: hipEventCreate failed");
+    if (!reserve_events(f0, (size_t)kChunks)) return fail(c, CRT_ERR_HIP, "crt_render: hipEventCreate failed");
     for (size_t off = 0; off < bytes; off += chunk, nchunks++) {
         const size_t len = off + chunk < bytes ? chunk : bytes - off;
-        ev[nchunks] = next_event(c);
-        HIPCHECK(c, hipMemcpyAsync(c->h_stage + off, (const unsigned char*)c->d_bgr + off, len, hipMemcpyDeviceToHost, c->stream));
+        ev[nchunks] = next_event(f0);
+        HIPCHECK(c, hipMemcpyAsync(c->h_stage + off, (const unsigned char*)f0.d_bgr + off, len, hipMemcpyDeviceToHost, c->stream));
         HIPCHECK(c, hipEventRecord(ev[nchunks], c->stream));
     }
-    c->evused -= nchunks;                            /* the events go back to the pool: they are done when this call returns */
+    f0.evused -= nchunks;                            /* the events go back to the pool: they are done when this call returns */
     std::thread workers[kThreads];
     hipError_t werr[kThreads];
     for (int t = 0; t < kThreads; t++) {
@@ -1085,20 +1213,22 @@ int crt_render(crt_ctx* c, const crt_camera* cam, const crt_params* p, unsigned 
 
 int crt_get_capture(crt_ctx* c, int bounce, int32_t* ids, float* ts, int npixels) {
     if (!c || !ids || !ts) return CRT_ERR_ARG;
-    if (!c->capture || !c->cap_ids) return fail(c, CRT_ERR_STATE, "crt_get_capture: capture was not enabled before the render");
-    if (bounce < 0 || bounce >= c->last_bounces || npixels != c->last_w * c->last_h) return fail(c, CRT_ERR_ARG, "crt_get_capture: bad bounce or size");
+    FrameSlot& f0 = c->fs[0];
+    if (!c->capture || !f0.cap_ids) return fail(c, CRT_ERR_STATE, "crt_get_capture: capture was not enabled before the render");
+    if (bounce < 0 || bounce >= f0.last_bounces || npixels != f0.last_w * f0.last_h) return fail(c, CRT_ERR_ARG, "crt_get_capture: bad bounce or size");
     HIPCHECK(c, hipSetDevice(c->device));
-    HIPCHECK(c, hipMemcpy(ids, c->cap_ids + (size_t)bounce * npixels, (size_t)npixels * 4, hipMemcpyDeviceToHost));
-    HIPCHECK(c, hipMemcpy(ts, c->cap_ts + (size_t)bounce * npixels, (size_t)npixels * 4, hipMemcpyDeviceToHost));
+    HIPCHECK(c, hipMemcpy(ids, f0.cap_ids + (size_t)bounce * npixels, (size_t)npixels * 4, hipMemcpyDeviceToHost));
+    HIPCHECK(c, hipMemcpy(ts, f0.cap_ts + (size_t)bounce * npixels, (size_t)npixels * 4, hipMemcpyDeviceToHost));
     return CRT_OK;
 }
 
 int crt_get_color(crt_ctx* c, float* rgb, int npixels) {
     if (!c || !rgb) return CRT_ERR_ARG;
-    if (!c->accum || npixels != c->last_w * c->last_h) return fail(c, CRT_ERR_ARG, "crt_get_color: no frame of that size");
+    FrameSlot& f0 = c->fs[0];
+    if (!f0.accum || npixels != f0.last_w * f0.last_h) return fail(c, CRT_ERR_ARG, "crt_get_color: no frame of that size");
     HIPCHECK(c, hipSetDevice(c->device));
     std::vector<float4> tmp(npixels);
-    HIPCHECK(c, hipMemcpy(tmp.data(), c->accum, (size_t)npixels * sizeof(float4), hipMemcpyDeviceToHost));
+    HIPCHECK(c, hipMemcpy(tmp.data(), f0.accum, (size_t)npixels * sizeof(float4), hipMemcpyDeviceToHost));
     for (int i = 0; i < npixels; i++) { rgb[3 * i] = tmp[i].x; rgb[3 * i + 1] = tmp[i].y; rgb[3 * i + 2] = tmp[i].z; }
     return CRT_OK;
 }
@@ -1125,15 +1255,15 @@ static int trace_hook(crt_ctx* c, const float* org_dir, int n, int32_t* prim_out
         TraceArgs ta{};
         ta.sv = view_of(c); ta.rayO = d_o; ta.rayD = d_d; ta.count = d_cnt; ta.next = d_cnt + 64;
         ta.hitSlot = d_slot; ta.hitT = d_t; ta.shflag = d_flag; ta.scene_abs = c->scene_abs;
-        ta.ovf = c->d_ovf; ta.ovf_depth = c->ovf_depth; ta.counters = c->d_testctr; ta.status = c->d_status;
+        ta.ovf = c->d_ovf; ta.ovf_depth = c->ovf_depth; ta.counters = c->d_testctr; ta.status = c->d_status; ta.block = c->trace_block;
         if (c->counting) TH(hipMemsetAsync(c->d_testctr, 0, 32 * sizeof(unsigned long long), c->stream));
         if (shadow_out && c->hdr.mode == CRT_BVH_WIDE) {      /* k_trace8 takes shadow rays in its second queue */
             ta.shO = d_o; ta.shD = d_d; ta.shcount = d_cnt;
             ta.rayO = nullptr; ta.rayD = nullptr; ta.count = nullptr;
         }
-        if (!reserve_events(c, 2)) { c->err = "crt_trace: hipEventCreate failed"; rc = CRT_ERR_HIP; goto done; }
-        hipEvent_t e0 = next_event(c), e1 = next_event(c);
-        c->evused -= 2;
+        if (!reserve_events(c->fs[0], 2)) { c->err = "crt_trace: hipEventCreate failed"; rc = CRT_ERR_HIP; goto done; }
+        hipEvent_t e0 = next_event(c->fs[0]), e1 = next_event(c->fs[0]);
+        c->fs[0].evused -= 2;
         TH(hipEventRecord(e0, c->stream));
         launch_trace(ta, shadow_out ? TRACE_SHADOW : TRACE_NEAREST, c->counting, c->hdr.mode == CRT_BVH_WIDE, c->grid_blocks, c->stream);
         TH(hipGetLastError());
@@ -1209,6 +1339,7 @@ int crt_blob_device_ptr(crt_ctx* c, void** p) {
 int crt_blob_import_device(crt_ctx* c, const void* dev_ptr, size_t bytes) {
     if (!c || !dev_ptr || bytes < sizeof(BlobHeader)) return fail(c, CRT_ERR_ARG, "crt_blob_import_device: bad arguments");
     HIPCHECK(c, hipSetDevice(c->device));
+    { const int rc = drain_frames(c); if (rc) return rc; }
     BlobHeader h;
     HIPCHECK(c, hipMemcpy(&h, dev_ptr, sizeof h, hipMemcpyDeviceToHost));
     if (h.magic != kBlobMagic || h.version != kBlobVersion || h.total_bytes != bytes) return fail(c, CRT_ERR_ARG, "crt_blob_import_device: not a scene blob of this version/size");
@@ -1237,7 +1368,8 @@ int crt_blob_import_device(crt_ctx* c, const void* dev_ptr, size_t bytes) {
 
 /* tile lists of every rank for the gather, resident on the device and cached per frame geometry */
 static int tile_list(crt_ctx* c, const crt_params* p, int rank, uint32_t** d_ids, int* ntiles) {
-    crt_params key = *p; key.rank = 0; key.bounces = 0; key.spp = 0; key.sort_rays = 0;
+    crt_params key{};          /* what the tile map depends on */
+    key.width = p->width; key.height = p->height; key.tile_w = p->tile_w; key.tile_h = p->tile_h; key.nranks = p->nranks;
     if (c->tl_ids.empty() || memcmp(&key, &c->tl_key, sizeof key) != 0) {
         HIPCHECK(c, hipStreamSynchronize(c->stream));
         for (uint32_t* q : c->tl_ids) if (q) hipFree(q);
@@ -1259,7 +1391,7 @@ static int tile_list(crt_ctx* c, const crt_params* p, int rank, uint32_t** d_ids
     return CRT_OK;
 }
 
-static int tiles_copy(crt_ctx* c, const crt_params* p, int src_rank, const void* src, void* dst, int to_packed) {
+static int tiles_copy(crt_ctx* c, const crt_params* p, int src_rank, const void* src, void* dst, int to_packed, hipStream_t stream, bool sync) {
     if (!c || !p || !src || !dst) return fail(c, CRT_ERR_ARG, "tiles pack/unpack: null argument");
     if (p->nranks < 1 || src_rank < 0 || src_rank >= p->nranks) return fail(c, CRT_ERR_ARG, "tiles pack/unpack: bad rank");
     HIPCHECK(c, hipSetDevice(c->device));
@@ -1269,18 +1401,37 @@ static int tiles_copy(crt_ctx* c, const crt_params* p, int src_rank, const void*
     FrameParams fp{};
     fp.width = p->width; fp.height = p->height; fp.tile_w = p->tile_w; fp.tile_h = p->tile_h;
     fp.tiles_x = (p->width + p->tile_w - 1) / p->tile_w; fp.ntiles_owned = nt;
-    launch_tiles_copy(fp, d_ids, nt, (const uint8_t*)src, (uint8_t*)dst, to_packed, c->stream);
+    launch_tiles_copy(fp, d_ids, nt, (const uint8_t*)src, (uint8_t*)dst, to_packed, stream ? stream : c->stream);
     HIPCHECK(c, hipGetLastError());
     /* packing is followed by a collective on another stream: finish it here.  Unpacks of several
      * ranks queue up on the context's stream; crt_sync() (or the next render) completes them. */
-    if (to_packed) HIPCHECK(c, hipStreamSynchronize(c->stream));
+    if (sync) HIPCHECK(c, hipStreamSynchronize(stream ? stream : c->stream));
     return CRT_OK;
 }
 int crt_tiles_pack(crt_ctx* c, const crt_params* p, const void* dev_bgr, void* dev_packed) {
-    return tiles_copy(c, p, p ? p->rank : 0, dev_bgr ? dev_bgr : (c ? c->d_bgr : nullptr), dev_packed, 1);
+    return tiles_copy(c, p, p ? p->rank : 0, dev_bgr ? dev_bgr : (c ? c->fs[0].d_bgr : nullptr), dev_packed, 1, nullptr, true);
 }
 int crt_tiles_unpack(crt_ctx* c, const crt_params* p, int src_rank, const void* dev_packed, void* dev_bgr) {
-    return tiles_copy(c, p, src_rank, dev_packed, dev_bgr, 0);
+    return tiles_copy(c, p, src_rank, dev_packed, dev_bgr, 0, nullptr, false);
+}
+/* the pack queued behind the frame a slot has in flight (or has just finished), on that slot's stream: complete when
+ * crt_render_wait(slot) returns -- or, for device-side consumers, when crt_slot_stream's work up to here is */
+int crt_tiles_pack_slot(crt_ctx* c, int slot, const crt_params* p, const void* dev_bgr, void* dev_packed) {
+    if (!c || slot < 0 || slot >= CRT_MAX_FRAME_SLOTS) return fail(c, CRT_ERR_ARG, "crt_tiles_pack_slot: bad slot");
+    FrameSlot& f = c->fs[slot];
+    if (!f.stream) return fail(c, CRT_ERR_STATE, "crt_tiles_pack_slot: nothing was ever submitted on this slot");
+    const int rc = tiles_copy(c, p, p ? p->rank : 0, dev_bgr ? dev_bgr : f.d_bgr, dev_packed, 1, f.stream, false);
+    if (rc) return rc;
+    if (f.in_flight) HIPCHECK(c, hipEventRecord(f.ev_done, f.stream));      /* the wait now covers the pack too */
+    return CRT_OK;
+}
+int crt_slot_stream(crt_ctx* c, int slot, void** hip_stream) {
+    if (!c || !hip_stream || slot < 0 || slot >= CRT_MAX_FRAME_SLOTS) return fail(c, CRT_ERR_ARG, "crt_slot_stream: bad arguments");
+    HIPCHECK(c, hipSetDevice(c->device));
+    const int rc = ensure_slot(c, slot);
+    if (rc) return rc;
+    *hip_stream = (void*)c->fs[slot].stream;
+    return CRT_OK;
 }
 
 int crt_get_stats(crt_ctx* c, crt_stats* out) { if (!c || !out) return CRT_ERR_ARG; *out = c->stats; return CRT_OK; }

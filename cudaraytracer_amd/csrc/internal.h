@@ -16,7 +16,8 @@ struct TraceView {
     unsigned long long* counters;
     uint32_t* status;                        /* device error word */
     uint32_t* h_status;                      /* pinned host word, allocated by crt_create */
-    int grid_blocks;
+    int grid_blocks;                         /* persistent grid in 256-thread blocks */
+    int block;                               /* threads per block of k_trace8 (256 / 128 / 64) */
 };
 int ctx_trace_view(crt_ctx* c, TraceView* out);          /* CRT_OK, or CRT_ERR_ARG for a null context */
 int ctx_fail(crt_ctx* c, int code, const char* msg);     /* records msg for crt_last_error and returns code */

@@ -54,6 +54,10 @@ constexpr int kRefillMinIdle8 = CRT_REFILL8_MIN_IDLE;
 constexpr int kStealMinIdle = CRT_STEAL_MIN_IDLE;
 constexpr int kStealEvery = CRT_STEAL_EVERY;
 constexpr int kStackDepth8 = CRT_STACK_DEPTH8;      /* k_trace8: 64-bit entries, at most one per tree level */
+/* in-LDS stack depth of the k_trace8 variant with `block` threads: chosen so that 5 waves per SIMD (20 per CU) fit the
+ * CU's 160 KB of LDS -- 256: 12 rows (30.7 KB x 5), 128: 11 rows (15.5 KB x 10), 64: 9 rows (7.7 KB x 20); deeper entries
+ * go to the per-thread overflow rows in HBM */
+constexpr int stack_depth8_of(int block) { return block >= 256 ? kStackDepth8 : (block == 128 ? (kStackDepth8 < 11 ? kStackDepth8 : 11) : (kStackDepth8 < 9 ? kStackDepth8 : 9)); }
 /* k_trace8 vote: a node step runs when n_node * PRIM_WEIGHT >= n_prim * NODE_WEIGHT */
 #ifndef CRT_VOTE8_PRIM_WEIGHT
 #define CRT_VOTE8_PRIM_WEIGHT 1
@@ -135,10 +139,12 @@ struct TraceArgs {
     unsigned long long* counters;            /* [0]=box [1]=tri [2]=sph tests [3]=node visits, when counting */
     uint32_t* status;            /* device error word: bit0 = stack overflow beyond ovf, bit1 = node not quantisable */
     int32_t steal_min_idle, steal_every;     /* k_trace8 tail (set by launch_trace): idle lanes that start a steal step; at most every n-th iteration */
+    int32_t block;                           /* k_trace8: threads per block, 256 (also 0) / 128 / 64 */
     int32_t tail_probe;                      /* CRT_TAIL_PROBE=1: waves report how long they ran after the queue was dry (counters[30], [31]) */
 };
 
 int trace_grid_blocks(int device);
+bool trace8_has_block(int block);
 void launch_trace(const TraceArgs& a, int mode, bool counting, bool wide, int blocks, hipStream_t s);
 void launch_quantize(const Node8* nodes, uint32_t nnodes, QNode8* qnodes, uint32_t* status, hipStream_t s);
 void launch_gen_primary(const FrameParams& fp, const FrameBuffers& fb, uint32_t* count, hipStream_t s);

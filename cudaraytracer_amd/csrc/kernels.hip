@@ -439,23 +439,31 @@ CRT_DEV void slab8(uint32_t& raw, uint32_t wnx, uint32_t wfx, uint32_t wny, uint
 #define CRT_MARK(NAME) asm volatile("; CRT_MARK " NAME);
 
 #if CRT_TRACE8_MIN_WAVES > 0
-#define CRT_TRACE8_BOUNDS __launch_bounds__(kTraceBlock, CRT_TRACE8_MIN_WAVES)
+#define CRT_TRACE8_BOUNDS __launch_bounds__(BLOCK, CRT_TRACE8_MIN_WAVES)
 #else
-#define CRT_TRACE8_BOUNDS __launch_bounds__(kTraceBlock)
+#define CRT_TRACE8_BOUNDS __launch_bounds__(BLOCK)
 #endif
-template <bool COUNT>
+/* BLOCK threads per block.  256 is what ships.  A block's registers and LDS come free only when its last wave ends, so
+ * 128- and 64-thread blocks (-DCRT_TRACE_BLOCK_VARIANTS, CRT_TRACE_BLOCK=128|64; the per-block octant table then costs
+ * more LDS, which a shallower in-LDS stack -- stack_depth8_of -- gives back so that 5 waves per SIMD still fit) were tried
+ * as a way to hand the tail of a launch to the frames other slots have in flight sooner.  Measured (round 3,
+ * profiles/r03_rank_slice_async.jsonl): the whole 4K frame 17.05 / 17.81 / 17.98 ms for 256 / 128 / 64, and with three frames of
+ * an eighth of it in flight 2.37 / 2.45 / 2.46 ms -- the same 0.90-0.91 of each variant's own ideal: what overlaps is not
+ * block retirement, so the fastest single launch wins */
+template <bool COUNT, int BLOCK>
 __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
-    __shared__ uint2 s_stack[kStackDepth8][kTraceBlock];
+    constexpr int kDepth = stack_depth8_of(BLOCK);
+    __shared__ uint2 s_stack[kDepth][BLOCK];
     __shared__ uint8_t s_perm[8][256];     /* s_perm[R][m]: bit k of m moved to bit k ^ R */
     /* work sharing in the tail (see "steal" below), indexed by the thread that OWNS the ray */
-    __shared__ unsigned long long s_key[kTraceBlock];      /* minimum over the ray's lanes: ordered t << 32 | rank, or a shadow outcome code */
-    __shared__ uint32_t s_cnt[kTraceBlock];                /* lanes still working on the ray */
-    __shared__ uint32_t s_best[kTraceBlock];               /* slot that holds the minimum */
-    __shared__ uint8_t s_pair[kTraceBlock];                /* steal step: the wave's offering lanes, compacted */
+    __shared__ unsigned long long s_key[BLOCK];      /* minimum over the ray's lanes: ordered t << 32 | rank, or a shadow outcome code */
+    __shared__ uint32_t s_cnt[BLOCK];                /* lanes still working on the ray */
+    __shared__ uint32_t s_best[BLOCK];               /* slot that holds the minimum */
+    __shared__ uint8_t s_pair[BLOCK];                /* steal step: the wave's offering lanes, compacted */
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wbase = tid & ~63;
-    for (int i = tid; i < 2048; i += kTraceBlock) {
+    for (int i = tid; i < 2048; i += BLOCK) {
         const int R_ = i >> 8, m = i & 255;
         int y = 0;
         for (int k = 0; k < 8; k++) if ((m >> k) & 1) y |= 1 << (k ^ R_);
@@ -470,7 +478,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
     const uint32_t total_s = A.shcount ? *A.shcount : 0u, total_n = A.count ? *A.count : 0u;
     const uint32_t ns64 = (total_s + (uint32_t)kFetchChunk - 1u) / (uint32_t)kFetchChunk * (uint32_t)kFetchChunk;
     const uint32_t total = ns64 + total_n;
-    const uint32_t gthread = blockIdx.x * kTraceBlock + tid;
+    const uint32_t gthread = blockIdx.x * BLOCK + tid;
     uint2* ovf = reinterpret_cast<uint2*>(A.ovf) + (size_t)gthread * (size_t)(A.ovf_depth > 0 ? A.ovf_depth : 0);
     const char* qbase = reinterpret_cast<const char*>(A.sv.qnodes);
 
@@ -529,7 +537,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
          *      area-sample shadow rays keep their lane (their predicate needs the one nearest hit's own arithmetic). ---- */
         if (amask != 0ull && ((++tick) & (uint32_t)(A.steal_every - 1)) == 0u && __popcll(amask) <= 64 - A.steal_min_idle) {
             const uint32_t nst = (fstate >> 16) & 15u;
-            const bool offer = active && (!(ray >> 31) || lkind == kShadowDirectional) && nst < 12u && (int)nst < kStackDepth8 && sp > (int)nst;
+            const bool offer = active && (!(ray >> 31) || lkind == kShadowDirectional) && nst < 12u && (int)nst < kDepth && sp > (int)nst;
             const unsigned long long omask = crt_ballot(offer);
             const int noffer = __popcll(omask);
             if (noffer > 0) {
@@ -649,8 +657,8 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                         else {
                             sp--;
                             uint2 e;
-                            if (sp < kStackDepth8) e = s_stack[sp][tid];
-                            else if (sp - kStackDepth8 < A.ovf_depth) e = ovf[sp - kStackDepth8];
+                            if (sp < kDepth) e = s_stack[sp][tid];
+                            else if (sp - kDepth < A.ovf_depth) e = ovf[sp - kDepth];
                             else { e = make_uint2(0u, 0u); finish = true; }
                             gbase = e.x; gmask = e.y;
                         }
@@ -662,8 +670,8 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                         gmask ^= 1u << pbit;
                         const uint32_t node = gbase + (uint32_t)__popc((gmask >> 8) & ((1u << slot) - 1u));
                         if (gmask & 0xffu) {
-                            if (sp < kStackDepth8) s_stack[sp][tid] = make_uint2(gbase, gmask);
-                            else if (sp - kStackDepth8 < A.ovf_depth) ovf[sp - kStackDepth8] = make_uint2(gbase, gmask);
+                            if (sp < kDepth) s_stack[sp][tid] = make_uint2(gbase, gmask);
+                            else if (sp - kDepth < A.ovf_depth) ovf[sp - kDepth] = make_uint2(gbase, gmask);
                             else atomicOr(A.status, 1u);
                             sp++;
                         }
@@ -919,10 +927,26 @@ int trace_grid_blocks(int device) {
     /* persistent grid = what is resident at once: limited by the LDS stack per block and by the
      * kernel's VGPR allocation; ask the runtime for the tighter of the two */
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace8<false>, kTraceBlock, 0) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace8<false, 256>, 256, 0) != hipSuccess || per_cu < 1)
         per_cu = 4;
     if (per_cu > 8) per_cu = 8;
     return p.multiProcessorCount * per_cu;
+}
+
+/* which block sizes this build holds: 256, and 128 / 64 with -DCRT_TRACE_BLOCK_VARIANTS (an experiment, see k_trace8) */
+bool trace8_has_block(int block) {
+#ifdef CRT_TRACE_BLOCK_VARIANTS
+    return block == 256 || block == 128 || block == 64;
+#else
+    return block == 256;
+#endif
+}
+
+template <int BLOCK>
+static void launch_trace8(const TraceArgs& a, bool counting, int blocks256, hipStream_t s) {
+    dim3 g((unsigned)(blocks256 * (256 / BLOCK))), b(BLOCK);      /* the same number of waves whatever the block size */
+    if (counting) hipLaunchKernelGGL((k_trace8<true, BLOCK>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_trace8<false, BLOCK>), g, b, 0, s, a);
 }
 
 void launch_trace(const TraceArgs& a_in, int mode, bool counting, bool wide, int blocks, hipStream_t s) {
@@ -935,8 +959,12 @@ void launch_trace(const TraceArgs& a_in, int mode, bool counting, bool wide, int
     static const int probe = getenv("CRT_TAIL_PROBE") ? 1 : 0;
     a.tail_probe = probe;
     if (wide) {          /* k_trace8 serves both of its queues in one launch; `mode` is not used */
-        if (counting) hipLaunchKernelGGL((k_trace8<true>), g, b, 0, s, a);
-        else hipLaunchKernelGGL((k_trace8<false>), g, b, 0, s, a);
+#ifdef CRT_TRACE_BLOCK_VARIANTS
+        if (a.block == 64) launch_trace8<64>(a, counting, blocks, s);
+        else if (a.block == 128) launch_trace8<128>(a, counting, blocks, s);
+        else
+#endif
+        launch_trace8<256>(a, counting, blocks, s);
     } else {
         if (mode == TRACE_NEAREST) {
             if (counting) hipLaunchKernelGGL((k_trace<TRACE_NEAREST, true>), g, b, 0, s, a);

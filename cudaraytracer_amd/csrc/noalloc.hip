@@ -96,6 +96,7 @@ extern "C" int crt_trace_noalloc(crt_ctx* c, const float* dev_org_dir, int n, in
     ta.sv = v.sv; ta.rayO = rayO; ta.rayD = rayD; ta.count = ctr; ta.next = ctr + 64;
     ta.hitSlot = slot; ta.hitT = dev_t_out; ta.shflag = nullptr; ta.scene_abs = v.scene_abs;
     ta.ovf = v.ovf; ta.ovf_depth = v.ovf_depth; ta.counters = v.counters; ta.status = v.status;
+    ta.block = v.block;
     launch_trace(ta, TRACE_NEAREST, false, v.wide, v.grid_blocks, v.stream);
     launch_slots_to_scene(slot, v.sv.sidx, dev_prim_out, (uint32_t)n, v.stream);
     NA_HIP(c, hipGetLastError());

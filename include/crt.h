@@ -79,7 +79,13 @@ typedef struct crt_params {
     int32_t use_graph;       /* 0/1: capture the frame's launch sequence in a HIP graph and replay it while camera, parameters,
                               * lights and buffers stay the same (scene contents may move: animation + refit).  For small,
                               * launch-bound frames; per-kernel times in crt_stats are then 0, ms_total stays */
-    int32_t reserved[5];
+    int32_t tile_sub, tile_nsub; /* tile_nsub > 1: this call renders only every tile_nsub-th tile of the rank's tile list, starting
+                              * at tile_sub (a frame split over several frame slots); the rank's tile map -- what pack / unpack
+                              * and the other ranks see -- is unchanged.  0, 0 */
+    int32_t grid_div;        /* > 1: the persistent traversal grid is the chip's resident capacity divided by this (frames in
+                              * flight on several slots share the chip side by side instead of taking turns).  0 */
+    int32_t timing;          /* 0: HIP events around every kernel (crt_stats ms_trace, ms_shade ...); 1: frame start / end only */
+    int32_t reserved[1];
 } crt_params;
 
 typedef struct crt_stats {
@@ -172,6 +178,20 @@ int crt_render(crt_ctx*, const crt_camera*, const crt_params*, unsigned char* bg
 /* same, leaving the frame in HBM: dev_bgr (width*height*3 device bytes) may be NULL to use the
  * context's own buffer; only this rank's tiles are written. */
 int crt_render_device(crt_ctx*, const crt_camera*, const crt_params*, void* dev_bgr);
+/* The same frame as two calls, for callers that keep several frames (or tile subsets of one frame: crt_params.tile_sub)
+ * in flight.  No counterpart in the reference, whose startRayTracing synchronises after every kernel (Ray.cu:698,718,720).
+ * A context has CRT_MAX_FRAME_SLOTS frame slots, each with a HIP stream and per-frame buffers of its own; slot 0 is the
+ * one crt_render / crt_render_device use (they are submit + wait on slot 0).  crt_render_submit queues the frame's whole
+ * launch sequence on the slot's stream and returns without waiting for the device (the first frame of a size on a slot
+ * allocates); crt_render_wait returns when that frame is complete, reports its errors and fills crt_get_stats.  A persistent
+ * traversal launch ends in a tail of its longest rays: with two or three slots in flight the launches of one frame run in
+ * the tails of the other's.  Frames on different slots may read the scene concurrently; calls that change the scene
+ * (crt_animate_device, crt_bvh_refit, crt_scene_update) are ordered behind frames already submitted and before frames
+ * submitted later, on the device; crt_bvh_build / crt_blob_import_device / crt_scene_set wait for them on the host.
+ * Counting (crt_set_counting) and crt_params.use_graph are for slot 0 only.  dev_bgr NULL = the slot's own frame. */
+#define CRT_MAX_FRAME_SLOTS 4
+int crt_render_submit(crt_ctx*, int slot, const crt_camera*, const crt_params*, void* dev_bgr);
+int crt_render_wait(crt_ctx*, int slot);
 /* float colour (RGB, before Ray.cu:724-731) and per-bounce nearest-hit ids/t of the last render,
  * for parity tests.  ids: scene index, -2-k for wall k, -1 none.  Enabled by crt_set_capture. */
 int crt_set_capture(crt_ctx*, int on);
@@ -213,6 +233,11 @@ int crt_tiles_owned(const crt_params*, int32_t* ntiles, int64_t* npixels, int32_
  * with the copy finished (a collective follows); unpacks queue on the context's stream: crt_sync() ends them. */
 int crt_tiles_pack(crt_ctx*, const crt_params*, const void* dev_bgr, void* dev_packed);
 int crt_tiles_unpack(crt_ctx*, const crt_params*, int src_rank, const void* dev_packed, void* dev_bgr);
+/* the pack queued on a frame slot's stream behind the frame submitted there, without waiting: crt_render_wait(slot)
+ * then returns with the packed tiles complete.  dev_bgr NULL = the slot's own frame */
+int crt_tiles_pack_slot(crt_ctx*, int slot, const crt_params*, const void* dev_bgr, void* dev_packed);
+/* the HIP stream of a frame slot (a hipStream_t), for host layers that queue their own copies / collectives behind a frame */
+int crt_slot_stream(crt_ctx*, int slot, void** hip_stream);
 
 int crt_get_stats(crt_ctx*, crt_stats*);
 int crt_sync(crt_ctx*);

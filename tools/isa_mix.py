@@ -18,10 +18,11 @@ against SQ_INSTS_VALU of the committed PMC pass.
 usage: tools/isa_mix.py kernels.s profiles/r02_ubench_valu_issue.jsonl out.json [waves_per_simd; 0 (default) = best over occupancies]
 """
 import json
+import os
 import re
 import sys
 
-KERNEL = "_ZN3crt8k_trace8ILb0EEEvNS_9TraceArgsE"
+KERNEL = os.environ.get("CRT_ISA_KERNEL", "_ZN3crt8k_trace8ILb0ELi256EEEvNS_9TraceArgsE")
 # opcodes the microbenchmark does not cover are priced by a measured sibling of the same encoding / unit
 SIBLING = {
     "v_cndmask_b32_e64": "v_cndmask_b32 SGPR-pair mask (VOP3)",
