@@ -163,6 +163,7 @@ def main():
     ap.add_argument("--bounces", type=int, default=3)
     ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--no-pipeline", action="store_true", help="N>1: finish every frame's tile gather before the next frame starts")
+    ap.add_argument("--slots", type=int, default=3, help="N>1: frames in flight per rank (crt_render_submit on frame slots 1..slots)")
     ap.add_argument("--bvh", type=int, default=0, help="0 wide SAH built on the host (default), 1 reference topology, 2 wide LBVH built on the device")
     ap.add_argument("--sort-rays", type=int, default=0, help="1: visit secondary rays in Morton order of their origin cell")
     ap.add_argument("--weak", action="store_true", help="N > 1: grow the frame with N at a fixed pixel count per GPU (weak scaling) "
@@ -223,7 +224,7 @@ def main():
         else:
             dist.init_process_group(backend)
         from cudaraytracer_amd.parallel import ShardedRenderer
-        sr = ShardedRenderer(dist, torch, rank, world, local_rank)
+        sr = ShardedRenderer(dist, torch, rank, world, local_rank, slots=a.slots)
         sr.broadcast_scene(prims, lights, a.bvh)
         ctx = sr.ctx
 
@@ -253,7 +254,7 @@ def main():
     # the timed kernels perform (same packed BVH, same order)
     log("scene + BVH resident; counting frame")
     ctx.set_counting(True)
-    step()
+    ctx.render_device(cam, tgt, params)          # this rank's tiles, alone on the context's own stream (the counters are one set per context)
     cst = ctx.stats()
     ctx.set_counting(False)
     log(f"counting frame done: device {cst['ms_total']:.2f} ms; warmup")
@@ -269,12 +270,23 @@ def main():
            "ms_other": 0.0, "launches_trace_nearest": 0, "launches_trace_shadow": 0, "launches_trace_mixed": 0}
     for _ in range(a.steps):
         step()
-        st = ctx.stats()
-        for k in acc:
-            acc[k] += st[k]
+        if world == 1:
+            st = ctx.stats()
+            for k in acc:
+                acc[k] += st[k]
     fence()
     elapsed = time.perf_counter() - t0
     log(f"timed steps done: {elapsed / a.steps * 1e3:.3f} ms/step")
+    if world > 1:
+        # N > 1 keeps several frames in flight per rank (frame slots): the intervals between per-kernel events then hold other
+        # frames' kernels too.  The per-kernel figures (frame_ms_split_rank0, the roofline's launch duration) come from this
+        # rank's frames rendered one at a time, after the timed region, with HIP events around every kernel
+        for _ in range(a.steps):
+            ctx.render_device(cam, tgt, params)
+            st = ctx.stats()
+            for k in acc:
+                acc[k] += st[k]
+        fence()
 
     rays = np.array([st["rays_primary"], st["rays_shadow"], st["rays_reflect"]], np.float64)
     per_rank = None
@@ -445,7 +457,10 @@ def main():
             "roofline": roof,
         }
         if per_rank is not None:
-            out["config"]["per_rank_ms"] = {"columns": ["device_render", "host_render_call", "tile_pack", "gather", "unpack"], "ranks": per_rank}
+            out["config"]["per_rank_ms"] = {"columns": ["device_render_one_frame_alone", "host_wait_for_render", "host_submit_and_pack_launch", "gather_issue", "gather_wait_and_unpack"],
+                                            "ranks": per_rank}
+            out["config"]["frames_in_flight_per_rank"] = 1 if a.no_pipeline else sr.K
+            out["config"]["per_kernel_times"] = "this rank's frames rendered one at a time after the timed region (frames in flight overlap each other's kernels)"
         if world == 1:
             # the PCIe-inclusive frame (crt_render: same kernels + device->host copy of the BGR frame);
             # reported beside, never as, `value`

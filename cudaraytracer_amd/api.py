@@ -71,6 +71,8 @@ class Stats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+MAX_FRAME_SLOTS = 4      # CRT_MAX_FRAME_SLOTS
+
 # every symbol include/crt.h declares; tests/test_abi.py checks the library exports all of them
 ABI_SYMBOLS = [
     "crt_create", "crt_destroy", "crt_last_error", "crt_params_default", "crt_set_counting",
@@ -83,6 +85,7 @@ ABI_SYMBOLS = [
     "crt_get_stats", "crt_sync",
     "crt_mgpu_create", "crt_mgpu_destroy", "crt_mgpu_size", "crt_mgpu_uses_rccl", "crt_mgpu_ctx", "crt_mgpu_last_error",
     "crt_mgpu_lights_set", "crt_mgpu_sync_scene", "crt_mgpu_render", "crt_mgpu_render_device", "crt_mgpu_get_times",
+    "crt_mgpu_scene_set", "crt_mgpu_animate", "crt_mgpu_submit", "crt_mgpu_finish",
     "crt_load_obj", "crt_scene_teapot", "crt_scene_spheres", "crt_scene_soup", "crt_lights_default", "crt_area_table",
     "crt_camera_default", "crt_animate_host", "crt_write_bmp", "crt_host_bvh",
 ]
@@ -138,6 +141,8 @@ for _name, _args in {
     "crt_mgpu_render": [_vp, C.POINTER(Camera), C.POINTER(Params), _vp],
     "crt_mgpu_render_device": [_vp, C.POINTER(Camera), C.POINTER(Params), C.POINTER(_vp)],
     "crt_mgpu_get_times": [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)],
+    "crt_mgpu_scene_set": [_vp, _vp, _i], "crt_mgpu_animate": [_vp, _i, _i],
+    "crt_mgpu_submit": [_vp, C.POINTER(Camera), C.POINTER(Params), C.POINTER(_vp)], "crt_mgpu_finish": [_vp, C.POINTER(_vp)],
 }.items():
     getattr(lib, _name).restype = _i
     getattr(lib, _name).argtypes = _args
@@ -495,6 +500,27 @@ class MultiGpu:
         c = Context._cam(cam, target)
         p = _vp(0)
         self._ck(lib.crt_mgpu_render_device(self.h, C.byref(c), C.byref(params), C.byref(p)))
+        return p.value
+
+    def set_scene(self, prims):
+        """crt_mgpu_scene_set: the scene on every rank (animate() then needs no exchange)"""
+        prims = np.ascontiguousarray(prims, PRIM_DTYPE)
+        self._ck(lib.crt_mgpu_scene_set(self.h, _ptr(prims), len(prims)))
+        self.root.nprims = len(prims)
+
+    def animate(self, rebuild=False, grow_only=False):
+        self._ck(lib.crt_mgpu_animate(self.h, int(rebuild), int(grow_only)))
+
+    def submit(self, cam, target, params):
+        """crt_mgpu_submit: returns the device address of the most recent frame completed by the call, or None"""
+        c = Context._cam(cam, target)
+        p = _vp(0)
+        self._ck(lib.crt_mgpu_submit(self.h, C.byref(c), C.byref(params), C.byref(p)))
+        return p.value
+
+    def finish(self):
+        p = _vp(0)
+        self._ck(lib.crt_mgpu_finish(self.h, C.byref(p)))
         return p.value
 
     def times(self):

@@ -30,6 +30,13 @@ crt_ctx* ctx() {
         std::vector<int> devs;
         for (int d = 0; d < want; d++) devs.push_back(d);
         g_mgpu = crt_mgpu_create(devs.empty() ? nullptr : devs.data(), (int)devs.size(), 0, &err);
+        if (!g_mgpu && devs.size() != 1) {
+            /* the multi-GPU layer could not come up (librccl missing, ncclCommInitAll failed ...): the reference is a
+             * single-GPU program, so one GPU -- which loads no RCCL at all -- is always a valid way to serve it */
+            fprintf(stderr, "CudaRayTracer compat: multi-GPU set-up failed (status %d); rendering on GPU 0 only\n", err);
+            const int one = 0;
+            g_mgpu = crt_mgpu_create(&one, 1, 0, &err);
+        }
         if (g_mgpu) g_ctx = crt_mgpu_ctx(g_mgpu, 0);
         if (!g_ctx) g_err = "crt_mgpu_create failed (no HIP device?)";
     }

@@ -113,6 +113,7 @@ struct crt_ctx {
     uint32_t* d_ovf = nullptr; size_t ovf_cap = 0; size_t ovf_slot_words = 0; int ovf_depth = 0;      /* one area per frame slot */
     int grid_blocks = 1024;            /* persistent traversal grid, in 256-thread blocks: what is resident at once */
     int trace_block = 256;             /* threads per block of k_trace8 (CRT_TRACE_BLOCK = 256 / 128 / 64) */
+    hipEvent_t refit_ev[2] = {nullptr, nullptr}; bool refit_pending = false;      /* ctx_refit_enqueue .. ctx_refit_finish */
     std::vector<uint32_t*> tl_ids; std::vector<int> tl_n; crt_params tl_key{};      /* per-rank tile lists for pack/unpack */
     crt_stats stats{};
 };
@@ -403,6 +404,48 @@ bool finite_geometry(const crt_prim* prims, int n) {
 
 namespace crt {
 int ctx_fail(crt_ctx* c, int code, const char* msg) { return fail(c, code, msg); }
+/* crt_bvh_refit in two halves, so that a host layer driving several contexts (mgpu.cpp) can queue the refit on every
+ * GPU before it waits for any: the launches + the copies of the new root box and the status word into pinned words ... */
+int ctx_refit_enqueue(crt_ctx* c, int grow_only) {
+    if (!c) return CRT_ERR_ARG;
+    if (!c->built) return fail(c, CRT_ERR_STATE, "crt_bvh_refit: no BVH (call crt_bvh_build)");
+    HIPCHECK(c, hipSetDevice(c->device));
+    char* b = (char*)c->d_blob;
+    { const int rc = order_after_frames(c); if (rc) return rc; }
+    FrameSlot& f0 = c->fs[0];
+    if (!reserve_events(f0, 2)) return fail(c, CRT_ERR_HIP, "crt_bvh_refit: hipEventCreate failed");
+    c->refit_ev[0] = next_event(f0); c->refit_ev[1] = next_event(f0);
+    f0.evused -= 2;
+    HIPCHECK(c, hipEventRecord(c->refit_ev[0], c->stream));
+    if (c->hdr.mode == CRT_BVH_WIDE) {
+        launch_refit8((Node8*)(b + c->hdr.off_nodes), c->hdr.nnodes, (const Geom*)(b + c->hdr.off_geom), c->d_arrive,
+                      (float*)(b + offsetof(BlobHeader, root_box)), grow_only ? 1 : 0, c->stream);
+        launch_quantize((const Node8*)(b + c->hdr.off_nodes), c->hdr.nnodes, (QNode8*)(b + c->hdr.off_qnodes), c->d_status, c->stream);
+    } else {
+        launch_refit((Node4*)(b + c->hdr.off_nodes), c->hdr.nnodes, (const Geom*)(b + c->hdr.off_geom), c->d_arrive,
+                     (float*)(b + offsetof(BlobHeader, root_box)), grow_only ? 1 : 0, c->stream);
+    }
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipEventRecord(c->refit_ev[1], c->stream));
+    HIPCHECK(c, hipMemcpyAsync(c->h_status + 8, b + offsetof(BlobHeader, root_box), 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(c->h_status + 1, c->d_status, 4, hipMemcpyDeviceToHost, c->stream));
+    c->refit_pending = true;
+    return CRT_OK;
+}
+/* ... and the wait: the root box (it scales the traversal's slab pad) and the status word reach the host */
+int ctx_refit_finish(crt_ctx* c) {
+    if (!c) return CRT_ERR_ARG;
+    if (!c->refit_pending) return fail(c, CRT_ERR_STATE, "crt_bvh_refit: nothing enqueued");
+    c->refit_pending = false;
+    HIPCHECK(c, hipSetDevice(c->device));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    float ms = 0; hipEventElapsedTime(&ms, c->refit_ev[0], c->refit_ev[1]); c->stats.ms_refit = ms;
+    memcpy(c->hdr.root_box, c->h_status + 8, 6 * sizeof(float));
+    scene_abs_from_box(c);
+    const uint32_t st = c->h_status[1];
+    c->h_status[1] = 0;
+    return status_error(c, st);
+}
 int ctx_trace_view(crt_ctx* c, TraceView* v) {
     if (!c || !v) return CRT_ERR_ARG;
     v->built = c->built;
@@ -730,31 +773,8 @@ int crt_bvh_build(crt_ctx* c, int mode) {
 }
 
 int crt_bvh_refit(crt_ctx* c, int grow_only) {
-    if (!c) return CRT_ERR_ARG;
-    if (!c->built) return fail(c, CRT_ERR_STATE, "crt_bvh_refit: no BVH (call crt_bvh_build)");
-    HIPCHECK(c, hipSetDevice(c->device));
-    char* b = (char*)c->d_blob;
-    { const int rc = order_after_frames(c); if (rc) return rc; }
-    FrameSlot& f0 = c->fs[0];
-    if (!reserve_events(f0, 2)) return fail(c, CRT_ERR_HIP, "crt_bvh_refit: hipEventCreate failed");
-    hipEvent_t e0 = next_event(f0), e1 = next_event(f0);
-    f0.evused -= 2;
-    HIPCHECK(c, hipEventRecord(e0, c->stream));
-    if (c->hdr.mode == CRT_BVH_WIDE) {
-        launch_refit8((Node8*)(b + c->hdr.off_nodes), c->hdr.nnodes, (const Geom*)(b + c->hdr.off_geom), c->d_arrive,
-                      (float*)(b + offsetof(BlobHeader, root_box)), grow_only ? 1 : 0, c->stream);
-        launch_quantize((const Node8*)(b + c->hdr.off_nodes), c->hdr.nnodes, (QNode8*)(b + c->hdr.off_qnodes), c->d_status, c->stream);
-    } else {
-        launch_refit((Node4*)(b + c->hdr.off_nodes), c->hdr.nnodes, (const Geom*)(b + c->hdr.off_geom), c->d_arrive,
-                     (float*)(b + offsetof(BlobHeader, root_box)), grow_only ? 1 : 0, c->stream);
-    }
-    HIPCHECK(c, hipGetLastError());
-    HIPCHECK(c, hipEventRecord(e1, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(c->hdr.root_box, b + offsetof(BlobHeader, root_box), sizeof c->hdr.root_box, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
-    float ms = 0; hipEventElapsedTime(&ms, e0, e1); c->stats.ms_refit = ms;
-    scene_abs_from_box(c);
-    return check_status(c);
+    const int rc = crt::ctx_refit_enqueue(c, grow_only);
+    return rc ? rc : crt::ctx_refit_finish(c);
 }
 
 int crt_bvh_free(crt_ctx* c) {

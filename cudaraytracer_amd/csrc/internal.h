@@ -20,7 +20,10 @@ struct TraceView {
     int block;                               /* threads per block of k_trace8 (256 / 128 / 64) */
 };
 int ctx_trace_view(crt_ctx* c, TraceView* out);          /* CRT_OK, or CRT_ERR_ARG for a null context */
-int ctx_fail(crt_ctx* c, int code, const char* msg);     /* records msg for crt_last_error and returns code */
+int ctx_fail(crt_ctx* c, int code, const char* msg);
+/* crt_bvh_refit as enqueue + wait (mgpu.cpp queues the refit on every GPU before it waits for any) */
+int ctx_refit_enqueue(crt_ctx* c, int grow_only);
+int ctx_refit_finish(crt_ctx* c);     /* records msg for crt_last_error and returns code */
 
 /* noalloc.hip: address of this device's copy of the scratch array, looked up once per device by crt_create
  * (with that device current); null + *err set if the lookup failed */

@@ -1,12 +1,18 @@
 /* mgpu.cpp -- the multi-GPU host layer in C++ over RCCL (BASELINE north_star: "frames shard by image
  * tile across the GPUs of one node, the BVH and scene replicated via RCCL broadcast, the framebuffer gathered over xGMI").
  *
- * One process, one crt_ctx per GPU, one host thread per GPU while a frame renders.  The path shards with no reduction:
+ * One process, one crt_ctx per GPU; frames are queued asynchronously, so one host thread drives every GPU (only the per-GPU
+ * device rebuilds of crt_mgpu_animate run on threads of their own).  The path shards with no reduction:
  *   crt_mgpu_sync_scene   ncclBroadcast of rank 0's packed scene + BVH blob (one contiguous device buffer, layout.h) to
  *                         every other rank, which imports it (crt_blob_import_device); lights are copied host-side
  *   crt_mgpu_render       every rank renders the 32x32 tiles it owns (crt_tile_owner) into its own device frame and packs
  *                         them tile-major; ONE grouped exchange -- ncclSend from every rank r > 0, ncclRecv x (R-1) on rank 0,
  *                         each over its own xGMI link -- brings them to rank 0, which scatters them into the bottom-up frame
+ *   crt_mgpu_submit/finish the same frame as a pipeline: K = 3 frames in flight per rank on the contexts' frame slots
+ *                         (crt_render_submit: the host thread queues every rank's launches and never blocks on one), the gather of
+ *                         a finished frame under the renders of later ones, 2K + 1 frame / 2K pack and gather buffers
+ *   crt_mgpu_animate      the per-frame scene update with no traffic at all: every rank replays the deterministic animation step
+ *                         on its own copy of the scene (crt_mgpu_scene_set) and refits / rebuilds locally
  * RCCL is loaded with dlopen on first use (RTLD_LOCAL: a process that also holds PyTorch's bundled RCCL keeps the two
  * apart) and not at all for one GPU unless CRT_MGPU_RCCL_ALWAYS asks for the 1-rank communicator.
  *
@@ -15,13 +21,17 @@
  * pack, unpack) is the code the real ranks run.
  */
 #include "../../include/crt.h"
+#include "internal.h"
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <mutex>
+#include <new>
+#include <system_error>
 #include <set>
 #include <string>
 #include <thread>
@@ -60,6 +70,13 @@ bool load_rccl(std::string& err) {
 
 }  // namespace
 
+/* one frame on its way through the pipeline of crt_mgpu_submit */
+struct MgpuFrame {
+    std::vector<crt_params> p;       /* per rank */
+    std::vector<size_t> pb;          /* packed bytes per rank */
+    int fb = 0, kb = 0, slot = 0;    /* frame buffer (rank 0: of 2K + 1, ranks > 0: of K), pack / gather buffer (of 2K), frame slot */
+};
+
 struct crt_mgpu {
     int n = 0;
     std::vector<int> dev;
@@ -67,14 +84,21 @@ struct crt_mgpu {
     std::vector<hipStream_t> stream;           /* one per rank, on its device: the collectives run here */
     std::vector<ncclComm_t> comm;              /* empty: local-copy transport (logical ranks, or one GPU without RCCL) */
     bool rccl = false;
+    bool self_exchange = false;                /* CRT_MGPU_RCCL_ALWAYS on one GPU: rank 0 sends its own tiles to itself through ncclSend / ncclRecv */
     std::vector<void*> blob_rx; std::vector<size_t> blob_rx_cap;      /* per rank > 0: where the broadcast blob lands */
-    std::vector<void*> frame; std::vector<size_t> frame_cap;          /* per rank: device frame (w*h*3), own tiles written */
-    std::vector<void*> packed; std::vector<size_t> packed_cap;        /* per rank: its tiles, tile-major */
-    std::vector<void*> gathered; std::vector<size_t> gathered_cap;    /* on rank 0's device, per source rank > 0 */
+    /* per rank, per buffer index: device frames (w*h*3, own tiles written), this rank's tiles tile-major, and -- on rank 0's
+     * device -- where each source rank's tiles land */
+    static constexpr int K = 3;                /* frames in flight per rank in crt_mgpu_submit (frame slots 1..K of every context) */
+    static constexpr int NB = 2 * K;
+    std::vector<std::vector<void*>> frame, packed, gathered;
+    std::vector<std::vector<size_t>> frame_cap, packed_cap, gathered_cap;
     std::vector<crt_light> lights;
     bool have_lights = false;
     std::string err;
     double ms_render = 0, ms_exchange = 0, ms_unpack = 0;
+    uint64_t seq = 0;
+    std::deque<MgpuFrame> inflight, gathering;
+    bool have_prims = false;                   /* crt_mgpu_scene_set: every rank holds the crt_prim array (crt_mgpu_animate needs it) */
 };
 
 namespace {
@@ -108,6 +132,107 @@ size_t packed_bytes(const crt_params* p, int rank) {
     return (size_t)nt * (size_t)q.tile_w * (size_t)q.tile_h * 3;
 }
 
+int rank_fail(crt_mgpu* m, int rc, const char* what, int r) {
+    return mfail(m, rc, std::string(what) + " on rank " + std::to_string(r) + ": " + crt_last_error(m->ctx[r]));
+}
+
+/* per-rank parameters, packed sizes and the buffers frame (fb, kb) needs */
+int prepare_frame(crt_mgpu* m, const crt_params* params, MgpuFrame& f) {
+    const int R = m->n;
+    const size_t fbytes = (size_t)params->width * (size_t)params->height * 3;
+    f.p.assign((size_t)R, *params); f.pb.assign((size_t)R, 0);
+    int rc;
+    for (int r = 0; r < R; r++) {
+        f.p[r].rank = r; f.p[r].nranks = R;
+        f.pb[r] = packed_bytes(&f.p[r], r);
+        const int fb = r == 0 ? f.fb : f.fb % crt_mgpu::K;
+        if ((rc = ensure_dev(m, m->dev[r], m->frame[r][fb], m->frame_cap[r][fb], fbytes))) return rc;
+        if (r > 0 || m->self_exchange) {
+            if ((rc = ensure_dev(m, m->dev[r], m->packed[r][f.kb], m->packed_cap[r][f.kb], f.pb[r] ? f.pb[r] : 16))) return rc;
+            if ((rc = ensure_dev(m, m->dev[0], m->gathered[r][f.kb], m->gathered_cap[r][f.kb], f.pb[r] ? f.pb[r] : 16))) return rc;
+        }
+    }
+    return CRT_OK;
+}
+void* frame_of(crt_mgpu* m, const MgpuFrame& f, int r) { return m->frame[r][r == 0 ? f.fb : f.fb % crt_mgpu::K]; }
+
+/* queue the frame on every rank's frame slot, each with its tile pack behind it: no waiting */
+int submit_frame(crt_mgpu* m, const crt_camera* cam, MgpuFrame& f) {
+    for (int r = 0; r < m->n; r++) {
+        int q = crt_render_submit(m->ctx[r], f.slot, cam, &f.p[r], frame_of(m, f, r));
+        if (q == CRT_OK && (r > 0 || m->self_exchange) && f.pb[r]) q = crt_tiles_pack_slot(m->ctx[r], f.slot, &f.p[r], frame_of(m, f, r), m->packed[r][f.kb]);
+        if (q) return rank_fail(m, q, "render", r);
+    }
+    return CRT_OK;
+}
+int wait_frame(crt_mgpu* m, MgpuFrame& f) {
+    int first = CRT_OK, at = 0;
+    for (int r = 0; r < m->n; r++) {        /* every rank is collected even after a failure: no slot stays busy */
+        const int q = crt_render_wait(m->ctx[r], f.slot);
+        if (q && !first) { first = q; at = r; }
+    }
+    return first ? rank_fail(m, first, "render", at) : CRT_OK;
+}
+/* the framebuffer gather: R - 1 point-to-point transfers into rank 0, each over its own link, as one group; queued on the
+ * ranks' collective streams, not waited for */
+int start_exchange(crt_mgpu* m, MgpuFrame& f) {
+    const int R = m->n;
+    const int first = m->self_exchange ? 0 : 1;
+    if (R == 1 && !m->self_exchange) return CRT_OK;
+    if (m->rccl) {
+        MNCCL(m, g_rccl.GroupStart());
+        for (int r = first; r < R; r++) {
+            if (!f.pb[r]) continue;
+            ncclResult_t q = g_rccl.Send(m->packed[r][f.kb], f.pb[r], ncclUint8, 0, m->comm[r], m->stream[r]);
+            if (q == ncclSuccess) q = g_rccl.Recv(m->gathered[r][f.kb], f.pb[r], ncclUint8, r, m->comm[0], m->stream[0]);
+            if (q != ncclSuccess) { g_rccl.GroupEnd(); return mfail(m, CRT_ERR_HIP, std::string("ncclSend/ncclRecv: ") + g_rccl.GetErrorString(q)); }
+        }
+        MNCCL(m, g_rccl.GroupEnd());
+    } else {
+        MHIP(m, hipSetDevice(m->dev[0]));
+        for (int r = first; r < R; r++)
+            if (f.pb[r]) {
+                if (m->dev[r] == m->dev[0]) MHIP(m, hipMemcpyAsync(m->gathered[r][f.kb], m->packed[r][f.kb], f.pb[r], hipMemcpyDeviceToDevice, m->stream[0]));
+                else MHIP(m, hipMemcpyPeerAsync(m->gathered[r][f.kb], m->dev[0], m->packed[r][f.kb], m->dev[r], f.pb[r], m->stream[0]));
+            }
+    }
+    return CRT_OK;
+}
+/* wait for the exchange and scatter the other ranks' tiles into rank 0's frame */
+int finish_exchange(crt_mgpu* m, MgpuFrame& f) {
+    const int R = m->n;
+    const int first = m->self_exchange ? 0 : 1;
+    if (R == 1 && !m->self_exchange) return CRT_OK;
+    for (int r = 0; r < R; r++) { MHIP(m, hipSetDevice(m->dev[r])); MHIP(m, hipStreamSynchronize(m->stream[r])); }
+    int rc;
+    for (int r = first; r < R; r++) {
+        if (!f.pb[r]) continue;
+        if ((rc = crt_tiles_unpack(m->ctx[0], &f.p[0], r, m->gathered[r][f.kb], frame_of(m, f, 0)))) return rank_fail(m, rc, "crt_tiles_unpack", 0);
+    }
+    if ((rc = crt_sync(m->ctx[0]))) return rank_fail(m, rc, "crt_sync", 0);
+    return CRT_OK;
+}
+
+/* oldest frame in flight: wait for its render + pack on every rank, start its gather; complete gathers older than `keep`
+ * frames.  *done = rank 0's frame of the last frame completed here, if any */
+int retire(crt_mgpu* m, size_t keep, void** done) {
+    int rc;
+    if (!m->inflight.empty()) {
+        MgpuFrame f = std::move(m->inflight.front());
+        m->inflight.pop_front();
+        if ((rc = wait_frame(m, f))) return rc;
+        if ((rc = start_exchange(m, f))) return rc;
+        m->gathering.push_back(std::move(f));
+    }
+    while (m->gathering.size() > keep) {
+        MgpuFrame f = std::move(m->gathering.front());
+        m->gathering.pop_front();
+        if ((rc = finish_exchange(m, f))) return rc;
+        if (done) *done = frame_of(m, f, 0);
+    }
+    return CRT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -120,12 +245,15 @@ crt_mgpu* crt_mgpu_create(const int* devices, int ndev, int flags, int* err) {
     if (!devices || ndev <= 0) { for (int d = 0; d < visible; d++) dev.push_back(d); }
     else dev.assign(devices, devices + ndev);
     for (int d : dev) if (d < 0 || d >= visible) return bail(CRT_ERR_ARG);
-    crt_mgpu* m = new crt_mgpu();
+    crt_mgpu* m = new (std::nothrow) crt_mgpu();
+    if (!m) return bail(CRT_ERR_NOMEM);
     m->n = (int)dev.size(); m->dev = dev;
     const size_t n = dev.size();
     m->ctx.assign(n, nullptr); m->stream.assign(n, nullptr);
-    m->blob_rx.assign(n, nullptr); m->blob_rx_cap.assign(n, 0); m->frame.assign(n, nullptr); m->frame_cap.assign(n, 0);
-    m->packed.assign(n, nullptr); m->packed_cap.assign(n, 0); m->gathered.assign(n, nullptr); m->gathered_cap.assign(n, 0);
+    m->blob_rx.assign(n, nullptr); m->blob_rx_cap.assign(n, 0);
+    m->frame.assign(n, std::vector<void*>(crt_mgpu::NB + 1, nullptr)); m->frame_cap.assign(n, std::vector<size_t>(crt_mgpu::NB + 1, 0));
+    m->packed.assign(n, std::vector<void*>(crt_mgpu::NB, nullptr)); m->packed_cap.assign(n, std::vector<size_t>(crt_mgpu::NB, 0));
+    m->gathered.assign(n, std::vector<void*>(crt_mgpu::NB, nullptr)); m->gathered_cap.assign(n, std::vector<size_t>(crt_mgpu::NB, 0));
     for (size_t r = 0; r < n; r++) {
         int e = 0;
         m->ctx[r] = crt_create(dev[r], &e);
@@ -146,6 +274,7 @@ crt_mgpu* crt_mgpu_create(const int* devices, int ndev, int flags, int* err) {
             return bail(CRT_ERR_HIP);
         }
         m->rccl = true;
+        m->self_exchange = n == 1;          /* rehearsal of the point-to-point calls where there is no second GPU */
     }
     if (err) *err = CRT_OK;
     return m;
@@ -155,10 +284,20 @@ void crt_mgpu_destroy(crt_mgpu* m) {
     if (!m) return;
     for (size_t r = 0; r < m->ctx.size(); r++) {
         if (r < m->dev.size()) (void)hipSetDevice(m->dev[r]);
+        if (m->ctx[r]) for (int k = 0; k < CRT_MAX_FRAME_SLOTS; k++) (void)crt_render_wait(m->ctx[r], k);      /* frames still in flight */
         if (r < m->stream.size() && m->stream[r]) { (void)hipStreamSynchronize(m->stream[r]); }
+    }
+    for (size_t r = 0; r < m->ctx.size(); r++) {
+        if (r < m->dev.size()) (void)hipSetDevice(m->dev[r]);
         if (m->rccl && r < m->comm.size() && m->comm[r]) g_rccl.CommDestroy(m->comm[r]);
-        void* bufs[] = {m->blob_rx[r], m->frame[r], m->packed[r], m->gathered[r]};
-        for (void* p : bufs) if (p) (void)hipFree(p);
+        if (m->blob_rx[r]) (void)hipFree(m->blob_rx[r]);
+        for (void* p : m->frame[r]) if (p) (void)hipFree(p);
+        for (void* p : m->packed[r]) if (p) (void)hipFree(p);
+    }
+    if (!m->dev.empty()) (void)hipSetDevice(m->dev[0]);
+    for (auto& v : m->gathered) for (void* p : v) if (p) (void)hipFree(p);      /* all on rank 0's device */
+    for (size_t r = 0; r < m->ctx.size(); r++) {
+        if (r < m->dev.size()) (void)hipSetDevice(m->dev[r]);
         if (r < m->stream.size() && m->stream[r]) (void)hipStreamDestroy(m->stream[r]);
         if (m->ctx[r]) crt_destroy(m->ctx[r]);
     }
@@ -175,8 +314,21 @@ int crt_mgpu_lights_set(crt_mgpu* m, const crt_light* lights, int n) {
     m->lights.assign(lights, lights + n); m->have_lights = true;
     for (int r = 0; r < m->n; r++) {
         const int rc = crt_lights_set(m->ctx[r], lights, n);
-        if (rc) return mfail(m, rc, std::string("crt_lights_set on rank ") + std::to_string(r) + ": " + crt_last_error(m->ctx[r]));
+        if (rc) return rank_fail(m, rc, "crt_lights_set", r);
     }
+    return CRT_OK;
+}
+
+/* The scene on EVERY rank (one process holds the host array, so this is R uploads, no collective): what crt_mgpu_animate
+ * needs, since the ranks then advance their own copy of the scene instead of receiving moved primitives.  Follow with
+ * crt_bvh_build on crt_mgpu_ctx(m, 0) and crt_mgpu_sync_scene, as for a scene set on rank 0 only. */
+int crt_mgpu_scene_set(crt_mgpu* m, const crt_prim* prims, int n) {
+    if (!m) return CRT_ERR_ARG;
+    int rc = crt_mgpu_finish(m, nullptr);
+    if (rc) return rc;
+    for (int r = 0; r < m->n; r++)
+        if ((rc = crt_scene_set(m->ctx[r], prims, n))) return rank_fail(m, rc, "crt_scene_set", r);
+    m->have_prims = true;
     return CRT_OK;
 }
 
@@ -190,10 +342,12 @@ int crt_mgpu_sync_scene(crt_mgpu* m) {
     for (int r = 1; r < m->n; r++)
         if ((rc = ensure_dev(m, m->dev[r], m->blob_rx[r], m->blob_rx_cap[r], bytes))) return rc;
     if (m->rccl) {
-        /* one broadcast, rank 0 in place: every rank's call inside one group, each on its own stream */
+        /* one broadcast, rank 0 in place: every rank's call inside one group, each on its own stream and with buffers on
+         * its own device (the send buffer is read on the root only) */
         MNCCL(m, g_rccl.GroupStart());
         for (int r = 0; r < m->n; r++) {
-            const ncclResult_t q = g_rccl.Broadcast(src, r == 0 ? src : m->blob_rx[r], bytes, ncclUint8, 0, m->comm[r], m->stream[r]);
+            void* buf = r == 0 ? src : m->blob_rx[r];
+            const ncclResult_t q = g_rccl.Broadcast(buf, buf, bytes, ncclUint8, 0, m->comm[r], m->stream[r]);
             if (q != ncclSuccess) { g_rccl.GroupEnd(); return mfail(m, CRT_ERR_HIP, std::string("ncclBroadcast: ") + g_rccl.GetErrorString(q)); }
         }
         MNCCL(m, g_rccl.GroupEnd());
@@ -206,88 +360,104 @@ int crt_mgpu_sync_scene(crt_mgpu* m) {
     }
     for (int r = 0; r < m->n; r++) { MHIP(m, hipSetDevice(m->dev[r])); MHIP(m, hipStreamSynchronize(m->stream[r])); }
     for (int r = 1; r < m->n; r++) {
-        if ((rc = crt_blob_import_device(m->ctx[r], m->blob_rx[r], bytes)))
-            return mfail(m, rc, std::string("crt_blob_import_device on rank ") + std::to_string(r) + ": " + crt_last_error(m->ctx[r]));
+        if ((rc = crt_blob_import_device(m->ctx[r], m->blob_rx[r], bytes))) return rank_fail(m, rc, "crt_blob_import_device", r);
+    }
+    return CRT_OK;
+}
+
+/* One step of the reference's frame loop for the scene (main.cu:534-541, 545-573) on every rank, with NO exchange: the
+ * animation step is deterministic, so every rank advances its own copy (crt_animate_device), then refits -- or, rebuild != 0
+ * (the "every 20th frame" of main.cu:534), rebuilds on its own device.  The refits are queued on all GPUs before any is
+ * waited for; the rebuilds run on one host thread per GPU.  Needs crt_mgpu_scene_set. */
+int crt_mgpu_animate(crt_mgpu* m, int rebuild, int grow_only) {
+    if (!m) return CRT_ERR_ARG;
+    if (!m->have_prims && m->n > 1) return mfail(m, CRT_ERR_STATE, "crt_mgpu_animate: only rank 0 holds the scene (crt_mgpu_scene_set hands it to every rank)");
+    int rc;
+    for (int r = 0; r < m->n; r++)
+        if ((rc = crt_animate_device(m->ctx[r]))) return rank_fail(m, rc, "crt_animate_device", r);
+    if (!rebuild) {
+        for (int r = 0; r < m->n; r++)
+            if ((rc = crt::ctx_refit_enqueue(m->ctx[r], grow_only))) return rank_fail(m, rc, "crt_bvh_refit", r);
+        int first = CRT_OK, at = 0;
+        for (int r = 0; r < m->n; r++) { rc = crt::ctx_refit_finish(m->ctx[r]); if (rc && !first) { first = rc; at = r; } }
+        return first ? rank_fail(m, first, "crt_bvh_refit", at) : CRT_OK;
+    }
+    std::vector<int> rcs((size_t)m->n, CRT_OK);
+    auto work = [&](int r) { rcs[r] = crt_bvh_build(m->ctx[r], CRT_BVH_WIDE_DEVICE); };
+    std::vector<std::thread> th;
+    try {
+        for (int r = 1; r < m->n; r++) th.emplace_back(work, r);
+    } catch (const std::system_error&) {          /* no thread to be had: the ranks not started build one after the other below */
+    }
+    work(0);
+    for (auto& t : th) t.join();
+    for (int r = (int)th.size() + 1; r < m->n; r++) work(r);
+    for (int r = 0; r < m->n; r++) if (rcs[r]) return rank_fail(m, rcs[r], "crt_bvh_build", r);
+    return CRT_OK;
+}
+
+/* Throughput mode: the frame is queued on every rank (render + tile pack on a frame slot's stream) and the call returns
+ * without waiting for it.  K = 3 frames are in flight per rank; when all slots are busy the oldest frame is waited for and
+ * its gather started on the collective streams, and gathers more than K frames old are completed and unpacked -- so the
+ * launches of one frame fill the tails of another's persistent launches and every gather runs under later renders.
+ * *dev_frame_done = rank 0's assembled frame of the last frame completed by this call (valid until the next call), or NULL. */
+int crt_mgpu_submit(crt_mgpu* m, const crt_camera* cam, const crt_params* params, void** dev_frame_done) {
+    if (!m || !cam || !params) return mfail(m, CRT_ERR_ARG, "crt_mgpu_submit: null argument");
+    if (dev_frame_done) *dev_frame_done = nullptr;
+    int rc;
+    if (m->inflight.size() >= (size_t)crt_mgpu::K && (rc = retire(m, (size_t)crt_mgpu::K, dev_frame_done))) return rc;
+    MgpuFrame f;
+    f.fb = (int)(m->seq % (crt_mgpu::NB + 1)); f.kb = (int)(m->seq % crt_mgpu::NB); f.slot = 1 + (int)(m->seq % crt_mgpu::K);
+    if ((rc = prepare_frame(m, params, f))) return rc;
+    for (auto& p : f.p) p.timing = 1;
+    if ((rc = submit_frame(m, cam, f))) return rc;
+    m->inflight.push_back(std::move(f));
+    m->seq++;
+    return CRT_OK;
+}
+
+/* completes every frame crt_mgpu_submit still has in flight; *dev_frame_last = the last one on rank 0's device */
+int crt_mgpu_finish(crt_mgpu* m, void** dev_frame_last) {
+    if (!m) return CRT_ERR_ARG;
+    if (dev_frame_last) *dev_frame_last = nullptr;
+    while (!m->inflight.empty() || !m->gathering.empty()) {
+        const int rc = retire(m, m->inflight.empty() ? 0 : (size_t)crt_mgpu::K, dev_frame_last);
+        if (rc) return rc;
     }
     return CRT_OK;
 }
 
 int crt_mgpu_render_device(crt_mgpu* m, const crt_camera* cam, const crt_params* params, void** dev_frame_rank0) {
     if (!m || !cam || !params) return mfail(m, CRT_ERR_ARG, "crt_mgpu_render: null argument");
-    const int R = m->n;
-    const size_t fbytes = (size_t)params->width * (size_t)params->height * 3;
-    std::vector<crt_params> p((size_t)R, *params);
-    std::vector<size_t> pb((size_t)R, 0);
     int rc;
-    for (int r = 0; r < R; r++) {
-        p[r].rank = r; p[r].nranks = R;
-        pb[r] = packed_bytes(&p[r], r);
-        if ((rc = ensure_dev(m, m->dev[r], m->frame[r], m->frame_cap[r], fbytes))) return rc;
-        if (r > 0) {
-            if ((rc = ensure_dev(m, m->dev[r], m->packed[r], m->packed_cap[r], pb[r] ? pb[r] : 16))) return rc;
-            if ((rc = ensure_dev(m, m->dev[0], m->gathered[r], m->gathered_cap[r], pb[r] ? pb[r] : 16))) return rc;
-        }
-    }
-    /* every rank renders and packs its tiles: one host thread per GPU (crt_render_device returns with the frame complete) */
-    std::vector<int> rcs((size_t)R, CRT_OK);
-    auto work = [&](int r) {
-        int q = crt_render_device(m->ctx[r], cam, &p[r], m->frame[r]);
-        if (q == CRT_OK && r > 0 && pb[r]) q = crt_tiles_pack(m->ctx[r], &p[r], m->frame[r], m->packed[r]);
-        rcs[r] = q;
-    };
+    if ((rc = crt_mgpu_finish(m, nullptr))) return rc;          /* frames of the throughput mode use the same buffers */
+    MgpuFrame f;
+    f.fb = 0; f.kb = 0; f.slot = 0;
+    if ((rc = prepare_frame(m, params, f))) return rc;
+    /* every rank renders and packs its tiles: the submissions return at once, the GPUs work side by side */
     const auto t0 = std::chrono::steady_clock::now();
-    if (R == 1) work(0);
-    else {
-        std::vector<std::thread> th;
-        for (int r = 1; r < R; r++) th.emplace_back(work, r);
-        work(0);
-        for (auto& t : th) t.join();
-    }
-    for (int r = 0; r < R; r++)
-        if (rcs[r]) return mfail(m, rcs[r], std::string("render on rank ") + std::to_string(r) + ": " + crt_last_error(m->ctx[r]));
+    if ((rc = submit_frame(m, cam, f))) { (void)wait_frame(m, f); return rc; }
+    if ((rc = wait_frame(m, f))) return rc;
     const auto t1 = std::chrono::steady_clock::now();
-    /* the framebuffer gather: R - 1 point-to-point transfers into rank 0, each over its own link, as one group */
-    if (R > 1) {
-        if (m->rccl) {
-            MNCCL(m, g_rccl.GroupStart());
-            for (int r = 1; r < R; r++) {
-                if (!pb[r]) continue;
-                ncclResult_t q = g_rccl.Send(m->packed[r], pb[r], ncclUint8, 0, m->comm[r], m->stream[r]);
-                if (q == ncclSuccess) q = g_rccl.Recv(m->gathered[r], pb[r], ncclUint8, r, m->comm[0], m->stream[0]);
-                if (q != ncclSuccess) { g_rccl.GroupEnd(); return mfail(m, CRT_ERR_HIP, std::string("ncclSend/ncclRecv: ") + g_rccl.GetErrorString(q)); }
-            }
-            MNCCL(m, g_rccl.GroupEnd());
-            for (int r = 0; r < R; r++) { MHIP(m, hipSetDevice(m->dev[r])); MHIP(m, hipStreamSynchronize(m->stream[r])); }
-        } else {
-            MHIP(m, hipSetDevice(m->dev[0]));
-            for (int r = 1; r < R; r++)
-                if (pb[r]) {
-                    if (m->dev[r] == m->dev[0]) MHIP(m, hipMemcpyAsync(m->gathered[r], m->packed[r], pb[r], hipMemcpyDeviceToDevice, m->stream[0]));
-                    else MHIP(m, hipMemcpyPeerAsync(m->gathered[r], m->dev[0], m->packed[r], m->dev[r], pb[r], m->stream[0]));
-                }
-            MHIP(m, hipStreamSynchronize(m->stream[0]));
-        }
-    }
+    if ((rc = start_exchange(m, f))) return rc;
+    for (int r = 0; r < m->n; r++) { MHIP(m, hipSetDevice(m->dev[r])); MHIP(m, hipStreamSynchronize(m->stream[r])); }
     const auto t2 = std::chrono::steady_clock::now();
-    for (int r = 1; r < R; r++) {
-        if (!pb[r]) continue;
-        if ((rc = crt_tiles_unpack(m->ctx[0], &p[0], r, m->gathered[r], m->frame[0])))
-            return mfail(m, rc, std::string("crt_tiles_unpack: ") + crt_last_error(m->ctx[0]));
-    }
-    if ((rc = crt_sync(m->ctx[0]))) return mfail(m, rc, crt_last_error(m->ctx[0]));
+    if ((rc = finish_exchange(m, f))) return rc;
     const auto t3 = std::chrono::steady_clock::now();
     m->ms_render = std::chrono::duration<double, std::milli>(t1 - t0).count();
     m->ms_exchange = std::chrono::duration<double, std::milli>(t2 - t1).count();
     m->ms_unpack = std::chrono::duration<double, std::milli>(t3 - t2).count();
-    if (dev_frame_rank0) *dev_frame_rank0 = m->frame[0];
+    if (dev_frame_rank0) *dev_frame_rank0 = frame_of(m, f, 0);
     return CRT_OK;
 }
 
 int crt_mgpu_render(crt_mgpu* m, const crt_camera* cam, const crt_params* params, unsigned char* bgr_out_host) {
-    if (!m || !bgr_out_host) return mfail(m, CRT_ERR_ARG, "crt_mgpu_render: null output buffer");
-    if (m->n == 1) {            /* one GPU: the single-context path with its pinned staging copy */
+    if (!m || !cam || !params || !bgr_out_host) return mfail(m, CRT_ERR_ARG, "crt_mgpu_render: null argument");
+    if (m->n == 1 && !m->self_exchange) {            /* one GPU: the single-context path with its pinned staging copy */
+        int rc = crt_mgpu_finish(m, nullptr);
+        if (rc) return rc;
         crt_params p = *params; p.rank = 0; p.nranks = 1;
-        const int rc = crt_render(m->ctx[0], cam, &p, bgr_out_host);
+        rc = crt_render(m->ctx[0], cam, &p, bgr_out_host);
         return rc ? mfail(m, rc, crt_last_error(m->ctx[0])) : CRT_OK;
     }
     void* f = nullptr;

@@ -77,9 +77,14 @@ def gather_frame_host(dist, params, local_packed, rank, world):
 
 
 class ShardedRenderer:
-    """Device path: one crt Context per rank, scene broadcast once, per-frame tile gather over RCCL."""
+    """Device path: one crt Context per rank, scene broadcast once, per-frame tile gather over RCCL.
 
-    def __init__(self, dist, torch, rank, world, local_rank):
+    render(..., pipelined=True) is the throughput mode bench.py uses: `slots` frames are in flight on the context's
+    frame slots 1..slots (crt_render_submit / crt_render_wait, each with the tile pack queued behind it), so that the
+    launches of one frame run in the tails of the others' persistent launches, and the gathers of finished frames run
+    under the renders of later ones.  Frames complete in order, `2 * slots` calls late at most; finish() drains."""
+
+    def __init__(self, dist, torch, rank, world, local_rank, slots=3):
         self.dist, self.torch, self.rank, self.world = dist, torch, rank, world
         self.dev = torch.device("cuda", local_rank)
         self.ctx = api.Context(local_rank)
@@ -88,15 +93,17 @@ class ShardedRenderer:
         self._hip.hipMemcpy.restype = C.c_int
         # RCCL gathers device tensors directly; gloo (the one-GPU rehearsal) has no device gather, so stage through the host
         self.host_gather = dist.get_backend() != "nccl"
+        self.K = max(1, min(int(slots), api.MAX_FRAME_SLOTS - 1))      # slot 0 (the context's own stream) stays free for the unpacks
         self.frame = None
-        self.frames = None          # two device frames (pipelined mode alternates), packed-tile and gather buffers alike
+        self.frames = None          # 2K + 1 device frames, 2K packed-tile and gather buffers: see render()
         self.packs = None
         self.gathers = None
-        self.packed = None
-        self.gathered = None
         self.sizes = None
-        self.pending = None         # pipelined mode: (params, buffer index, collective work, keep-alive) of the frame in flight
-        self.flip = 0
+        self.npix = None
+        self.seq = 0                # frames submitted in pipelined mode
+        self.inflight = []          # (params, frame buffer, pack buffer, slot) of frames being rendered, oldest first
+        self.gathering = []         # (params, frame buffer, pack buffer, work, keep-alive) of frames being gathered, oldest first
+        self.last_stats = None      # crt_stats of the frame whose render completed last
 
     def _bcast_bytes(self, payload):
         """broadcast a bytes-like object from rank 0 (device tensors: RCCL has no host path)"""
@@ -163,18 +170,18 @@ class ShardedRenderer:
     def _ensure(self, params):
         torch = self.torch
         npix = params.width * params.height
-        if self.frames is None or self.frames[0].numel() != npix * 3:
-            self.frames = [torch.zeros(npix * 3, dtype=torch.uint8, device=self.dev) for _ in range(2)]
-            self.frame = self.frames[0]
         sizes = [packed_nbytes(params, r) for r in range(self.world)]
-        if self.sizes != sizes:
-            self.finish()
-            self.sizes = sizes
-            mx = max(sizes)
-            self.packs = [torch.zeros(mx, dtype=torch.uint8, device=self.dev) for _ in range(2)]
-            self.gathers = [[torch.zeros(mx, dtype=torch.uint8, device=self.dev) for _ in range(self.world)] for _ in range(2)] \
-                if self.rank == 0 else [None, None]
-            self.packed, self.gathered = self.packs[0], self.gathers[0]
+        if self.npix == npix and self.sizes == sizes:
+            return
+        self.finish()               # frames in flight belong to the old buffers: complete them before anything is replaced
+        self.npix, self.sizes = npix, sizes
+        nb = 2 * self.K
+        self.frames = [torch.zeros(npix * 3, dtype=torch.uint8, device=self.dev) for _ in range(nb + 1)]
+        self.frame = self.frames[0]
+        mx = max(sizes)
+        self.packs = [torch.zeros(mx, dtype=torch.uint8, device=self.dev) for _ in range(nb)]
+        self.gathers = [[torch.zeros(mx, dtype=torch.uint8, device=self.dev) for _ in range(self.world)] for _ in range(nb)] \
+            if self.rank == 0 else [None] * nb
 
     def _gather(self, packed, gathered, async_op):
         """gather of the packed tiles to rank 0; returns (work or None, keepalive)"""
@@ -186,66 +193,111 @@ class ShardedRenderer:
         w = self.dist.gather(packed, gathered, dst=0, async_op=async_op)
         return w, None
 
-    def _complete(self, params, k, work, keep):
-        """wait for gather k and scatter the other ranks' tiles into frame k (rank 0)"""
+    def _complete(self, params, fb, pb, work, keep):
+        """wait for a gather and scatter the other ranks' tiles into the frame (rank 0)"""
         if work is not None:
             work.wait()
         if self.host_gather and self.rank == 0:
             for r in range(1, self.world):
-                self.gathers[k][r].copy_(keep[1][r])
-        # every rank waits for its part of the gather: a later frame packs into the same buffer on another stream
-        self.torch.cuda.synchronize(self.dev)
+                self.gathers[pb][r].copy_(keep[1][r])
+        # every rank waits for its part of the gather (a later frame packs into the same buffer on another stream).  The
+        # collective's own stream only: a device-wide synchronise would also wait for the frames in flight
+        self.torch.cuda.current_stream(self.dev).synchronize()
         if self.rank == 0:
             for r in range(1, self.world):
-                self.ctx.tiles_unpack(params, r, self.gathers[k][r].data_ptr(), self.frames[k].data_ptr())
+                self.ctx.tiles_unpack(params, r, self.gathers[pb][r].data_ptr(), self.frames[fb].data_ptr())
             self.ctx.sync()
 
+    def _retire(self, phase=None, keep_gathers=None):
+        """oldest frame in flight: wait for its render + pack, start its gather; complete gathers beyond `keep_gathers`.
+        Returns the frame buffer index of the last frame completed here, or None."""
+        import time
+        done = None
+        if self.inflight:
+            params, fb, pb, slot = self.inflight.pop(0)
+            t0 = time.perf_counter()
+            self.ctx.render_wait(slot)
+            self.last_stats = self.ctx.stats()
+            t1 = time.perf_counter()
+            if self.world == 1:
+                done = fb
+            else:
+                work, keep = self._gather(self.packs[pb], self.gathers[pb], async_op=True)
+                self.gathering.append((params, fb, pb, work, keep))
+            if phase is not None:
+                phase["render"] = phase.get("render", 0.0) + (t1 - t0)
+                phase["gather"] = phase.get("gather", 0.0) + (time.perf_counter() - t1)
+        limit = self.K if keep_gathers is None else keep_gathers
+        while len(self.gathering) > limit:
+            params, fb, pb, work, keep = self.gathering.pop(0)
+            t0 = time.perf_counter()
+            self._complete(params, fb, pb, work, keep)
+            if phase is not None:
+                phase["unpack"] = phase.get("unpack", 0.0) + (time.perf_counter() - t0)
+            done = fb
+        return done
+
     def finish(self):
-        """pipelined mode: complete the frame whose gather is still in flight; returns it on rank 0"""
-        if self.pending is None:
+        """pipelined mode: complete every frame still in flight; returns the last one on rank 0"""
+        done = None
+        while self.inflight or self.gathering:
+            d = self._retire(keep_gathers=0 if not self.inflight else None)
+            done = d if d is not None else done
+        if done is None:
             return None
-        params, k, work, keep = self.pending
-        self.pending = None
-        self._complete(params, k, work, keep)
-        return self.frames[k] if self.rank == 0 else None
+        self.frame = self.frames[done]
+        return self.frame if self.rank == 0 else None
 
     def render(self, cam, target, params, phase=None, pipelined=False):
         """Render this rank's tiles, gather to rank 0.  Returns the device frame tensor on rank 0.
         `phase` (optional dict) accumulates this rank's wall seconds per phase: render, pack, gather, unpack.
 
-        pipelined=True: the gather of frame k runs (asynchronously, on the collective's own stream) under the render of
-        frame k+1 -- frames, packed tiles and gather buffers are double buffered -- and the call returns the PREVIOUS
-        frame, complete, or None on the first call; finish() completes the last one.  Throughput mode for bench.py:
-        a step then costs max(render, exchange) instead of their sum."""
+        pipelined=True: the frame is SUBMITTED on the next of K frame slots (render and tile pack queued on the slot's
+        stream, no wait).  When all K slots are busy the oldest frame is waited for first and its gather started
+        (asynchronously, on the collective's own stream); gathers more than K frames old are completed and unpacked.
+        Frame i renders into frame buffer i mod (2K + 1) and packs into pack buffer i mod 2K: its gather is complete
+        before frame i + 2K packs.  The call returns the most recent frame completed by it (the frame submitted 2K calls
+        earlier, in steady state), or None; finish() completes the rest.  Throughput mode for bench.py: a step then costs
+        max(render, exchange) with the launch tails of one frame filled by the next, instead of their sum."""
         import time
         params.rank, params.nranks = self.rank, self.world
         self._ensure(params)
-        k = self.flip if pipelined else 0
-        self.frame = self.frames[k]
+        if pipelined:
+            t0 = time.perf_counter()
+            done = self._retire(phase) if len(self.inflight) >= self.K else None
+            t1 = time.perf_counter()
+            nb = 2 * self.K
+            fb, pb, slot = self.seq % (nb + 1), self.seq % nb, 1 + self.seq % self.K
+            q = api.Params.from_buffer_copy(params)
+            q.timing = 1                      # frame start / end events only: per-kernel intervals mean nothing between overlapping frames
+            self.ctx.render_submit(slot, cam, target, q, self.frames[fb].data_ptr())
+            if self.world > 1:
+                self.ctx.tiles_pack_slot(slot, q, self.frames[fb].data_ptr(), self.packs[pb].data_ptr())
+            self.inflight.append((q, fb, pb, slot))
+            self.seq += 1
+            if phase is not None:
+                phase["pack"] = phase.get("pack", 0.0) + (time.perf_counter() - t1)      # host time of submit + pack launch
+            if done is None:
+                return None
+            self.frame = self.frames[done]
+            return self.frame if self.rank == 0 else None
+        self.finish()                          # a frame still in flight from pipelined calls uses the same buffers
+        self.frame = self.frames[0]
         t0 = time.perf_counter()
-        self.ctx.render_device(cam, target, params, self.frames[k].data_ptr())       # returns with the frame complete
+        self.ctx.render_device(cam, target, params, self.frames[0].data_ptr())       # returns with the frame complete
+        self.last_stats = self.ctx.stats()
         t1 = time.perf_counter()
         if phase is not None:
             phase["render"] = phase.get("render", 0.0) + (t1 - t0)
         if self.world == 1:
-            return self.frames[k]
-        prev = self.finish() if pipelined else None      # frame k-1: its gather ran under this frame's render
-        t1b = time.perf_counter()
-        self.ctx.tiles_pack(params, self.frames[k].data_ptr(), self.packs[k].data_ptr())     # returns with the copy finished
+            return self.frames[0]
+        self.ctx.tiles_pack(params, self.frames[0].data_ptr(), self.packs[0].data_ptr())     # returns with the copy finished
         t2 = time.perf_counter()
-        work, keep = self._gather(self.packs[k], self.gathers[k], async_op=pipelined)
-        if pipelined:
-            self.pending = (api.Params.from_buffer_copy(params), k, work, keep)
-            self.flip ^= 1
-            t3 = time.perf_counter()
-            if phase is not None:
-                phase["pack"] = phase.get("pack", 0.0) + (t2 - t1b)
-                phase["gather"] = phase.get("gather", 0.0) + (t1b - t1) + (t3 - t2)      # exposed part: wait for k-1 + issue of k
-            return prev
+        work, keep = self._gather(self.packs[0], self.gathers[0], async_op=False)
         t3 = time.perf_counter()
-        self._complete(params, k, None, keep)
+        self._complete(params, 0, 0, None, keep)
         if phase is not None:
             phase["pack"] = phase.get("pack", 0.0) + (t2 - t1)
             phase["gather"] = phase.get("gather", 0.0) + (t3 - t2)
             phase["unpack"] = phase.get("unpack", 0.0) + (time.perf_counter() - t3)
-        return self.frames[k] if self.rank == 0 else None
+        return self.frames[0] if self.rank == 0 else None

@@ -246,8 +246,10 @@ int crt_sync(crt_ctx*);
  *      reference, which is single-GPU: startRayTracing in compat/ uses this layer when more than one GPU is visible).
  *      One crt_ctx per device; rank 0's context owns the scene (crt_scene_set / crt_bvh_build / crt_bvh_refit /
  *      crt_animate_device on crt_mgpu_ctx(m, 0)), crt_mgpu_sync_scene replicates it with ONE ncclBroadcast of the
- *      packed blob, crt_mgpu_render renders every rank's tiles on its own host thread and gathers them to rank 0 with
- *      one group of ncclSend / ncclRecv (R - 1 point-to-point transfers, each over its own xGMI link).  No reduction.
+ *      packed blob, crt_mgpu_render queues every rank's tiles (crt_render_submit: one host thread drives all GPUs) and gathers
+ *      them to rank 0 with one group of ncclSend / ncclRecv (R - 1 point-to-point transfers, each over its own xGMI link).
+ *      No reduction.  With CRT_MGPU_RCCL_ALWAYS on ONE GPU rank 0 sends its own tiles to itself through the same grouped
+ *      ncclSend / ncclRecv (a rehearsal of the calls where there is no second GPU).
  *      devices = NULL: all visible GPUs.  A list with repeats (e.g. {0,0,0}) makes logical ranks on one GPU for
  *      rehearsal: RCCL refuses duplicate devices, so the two exchanges become device-to-device copies. ---- */
 typedef struct crt_mgpu crt_mgpu;
@@ -259,10 +261,27 @@ int crt_mgpu_uses_rccl(const crt_mgpu*);                       /* 1: RCCL commun
 crt_ctx* crt_mgpu_ctx(crt_mgpu*, int rank);
 const char* crt_mgpu_last_error(crt_mgpu*);
 int crt_mgpu_lights_set(crt_mgpu*, const crt_light* lights, int n);
-int crt_mgpu_sync_scene(crt_mgpu*);                            /* after every build / refit / animation step on rank 0 */
+int crt_mgpu_sync_scene(crt_mgpu*);                            /* after every build on rank 0 (and after refit / animation steps done on rank 0 ONLY) */
+/* The scene on every rank instead of rank 0 only (R uploads from the one host array, no collective) -- what crt_mgpu_animate
+ * needs.  Then crt_bvh_build on crt_mgpu_ctx(m, 0) + crt_mgpu_sync_scene as usual. */
+int crt_mgpu_scene_set(crt_mgpu*, const crt_prim* prims, int n);
+/* The per-frame update of main.cu:534-541 + 545-573 with no traffic between GPUs (SURVEY.md 8(e) collective (2), the
+ * "replicate the deterministic animation step" form): every rank runs crt_animate_device on its own copy of the scene,
+ * then crt_bvh_refit(grow_only) -- queued on every GPU before any is waited for -- or, rebuild != 0, crt_bvh_build(
+ * CRT_BVH_WIDE_DEVICE) on its own device (one host thread per GPU).  No crt_mgpu_sync_scene afterwards. */
+int crt_mgpu_animate(crt_mgpu*, int rebuild, int grow_only);
 int crt_mgpu_render(crt_mgpu*, const crt_camera*, const crt_params*, unsigned char* bgr_out_host);
 /* leaves the assembled frame on rank 0's device (its address in *dev_frame_rank0, valid until the next render) */
 int crt_mgpu_render_device(crt_mgpu*, const crt_camera*, const crt_params*, void** dev_frame_rank0);
+/* Throughput mode of the same frame: crt_mgpu_submit queues the frame on every rank (render + tile pack on one of three
+ * frame slots per context) and returns without waiting; once three frames are in flight it first collects the oldest and
+ * starts its gather, and completes gathers more than three frames old -- the launches of one frame run in the tails of the
+ * others', every gather under later renders.  *dev_frame_done = rank 0's assembled frame of the most recent frame this call
+ * completed (frames complete in submission order; valid until the next crt_mgpu_* call), or NULL.  crt_mgpu_finish
+ * completes what is still in flight and returns the last frame.  Scene changes between submissions (crt_mgpu_animate) are
+ * ordered on the device behind the frames already submitted. */
+int crt_mgpu_submit(crt_mgpu*, const crt_camera*, const crt_params*, void** dev_frame_done);
+int crt_mgpu_finish(crt_mgpu*, void** dev_frame_last);
 /* wall milliseconds of the last crt_mgpu_render_device: all ranks' render + pack, the gather, the unpack on rank 0 */
 int crt_mgpu_get_times(crt_mgpu*, double* ms_render, double* ms_exchange, double* ms_unpack);
 

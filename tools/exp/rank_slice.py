@@ -69,11 +69,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "async":
     for _ in range(5): ctx.render_device(cam, tgt, p1)
     full = (time.perf_counter() - t0) / 5 * 1e3
     print(json.dumps({"mode": "full_frame_sync", "block": block, "wall_ms": round(full, 3)}), flush=True)
-    for nr in (8, 4):
+    which = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [8, 4]
+    brief = len(sys.argv) > 3
+    for nr in which:
         run_async(nr, 1, "frames", 1, full)
         for K in (2, 3, 4):
-            for mode in ("frames", "subframes"):
-                for div in (1, K):
+            for mode in ("frames",) if brief else ("frames", "subframes"):
+                for div in (1,) if brief else (1, K):
                     run_async(nr, K, mode, div, full)
 else:
     sync_table()
