@@ -77,7 +77,7 @@ MAX_FRAME_SLOTS = 4      # CRT_MAX_FRAME_SLOTS
 ABI_SYMBOLS = [
     "crt_create", "crt_destroy", "crt_last_error", "crt_params_default", "crt_set_counting",
     "crt_scene_set", "crt_scene_update", "crt_lights_set", "crt_animate_device", "crt_scene_get",
-    "crt_bvh_build", "crt_bvh_refit", "crt_bvh_free", "crt_bvh_reference_order", "crt_bvh_dump",
+    "crt_bvh_build", "crt_bvh_build_async", "crt_bvh_swap", "crt_bvh_refit", "crt_bvh_free", "crt_bvh_reference_order", "crt_bvh_dump",
     "crt_render", "crt_render_device", "crt_render_submit", "crt_render_wait", "crt_set_capture", "crt_get_capture", "crt_get_color",
     "crt_trace", "crt_trace_shadow", "crt_trace_noalloc", "crt_powf_probe",
     "crt_blob_size", "crt_blob_device_ptr", "crt_blob_import_device",
@@ -106,6 +106,7 @@ for _name, _args in {
     "crt_scene_set": [_vp, _vp, _i], "crt_scene_update": [_vp, _vp, _i], "crt_lights_set": [_vp, _vp, _i],
     "crt_animate_device": [_vp], "crt_scene_get": [_vp, _vp, _i],
     "crt_bvh_build": [_vp, _i], "crt_bvh_refit": [_vp, _i], "crt_bvh_free": [_vp],
+    "crt_bvh_build_async": [_vp], "crt_bvh_swap": [_vp, _i, C.POINTER(_i)],
     "crt_bvh_reference_order": [_vp, _vp, _i], "crt_bvh_dump": [_vp, _vp, _vp, _vp, _vp, _i],
     "crt_render": [_vp, C.POINTER(Camera), C.POINTER(Params), _vp],
     "crt_render_device": [_vp, C.POINTER(Camera), C.POINTER(Params), _vp],
@@ -339,6 +340,16 @@ class Context:
 
     def build(self, mode=0):
         self._ck(lib.crt_bvh_build(self.h, mode))
+
+    def build_async(self):
+        """crt_bvh_build_async: device rebuild from a snapshot of the scene, under the frames that follow"""
+        self._ck(lib.crt_bvh_build_async(self.h))
+
+    def swap(self, wait=False):
+        """crt_bvh_swap: True when the asynchronously built tree became current (it is refitted: skip this frame's refit)"""
+        sw = _i(0)
+        self._ck(lib.crt_bvh_swap(self.h, int(wait), C.byref(sw)))
+        return bool(sw.value)
 
     def refit(self, grow_only=False):
         self._ck(lib.crt_bvh_refit(self.h, int(grow_only)))

@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <thread>
+#include <atomic>
 
 using namespace crt;
 
@@ -47,7 +48,7 @@ struct FrameSlot {
     float4 *rayO[2] = {nullptr, nullptr}, *rayD[2] = {nullptr, nullptr}, *coef[2] = {nullptr, nullptr};
     uint32_t* pix[2] = {nullptr, nullptr};
     int32_t* hitSlot = nullptr; float* hitT = nullptr;
-    float4 *rc = nullptr, *contrib = nullptr, *shO = nullptr, *shD = nullptr, *accum = nullptr, *sum = nullptr;
+    float4 *contrib = nullptr, *shO = nullptr, *shD = nullptr, *accum = nullptr, *sum = nullptr;
     uint8_t* shflag = nullptr;
     /* crt_params.use_graph: the frame's launch sequence captured once and replayed while nothing but the scene's
      * contents changes */
@@ -71,6 +72,13 @@ struct FrameSlot {
     crt_params sub_p{}; int sub_spp = 1; bool sub_counting = false; int sub_grid = 0;
     int last_w = 0, last_h = 0, last_bounces = 0;
     bool light_timing = false;       /* crt_params.timing == 1 */
+};
+
+/* one device build (device_build_core): where it runs, what it reads, where the tree goes */
+struct DevBuild {
+    hipStream_t s; const crt_prim* prims; bool pack;      /* in: stream, scene to build from, whether to pack geometry too */
+    void* blob; size_t blob_cap;                          /* in/out: target blob (reallocated when too small) */
+    BlobHeader hdr; bool rank_valid; uint32_t levels; double ms;      /* out */
 };
 
 struct crt_ctx {
@@ -113,10 +121,24 @@ struct crt_ctx {
     uint32_t* d_ovf = nullptr; size_t ovf_cap = 0; size_t ovf_slot_words = 0; int ovf_depth = 0;      /* one area per frame slot */
     int grid_blocks = 1024;            /* persistent traversal grid, in 256-thread blocks: what is resident at once */
     int trace_block = 256;             /* threads per block of k_trace8 (CRT_TRACE_BLOCK = 256 / 128 / 64) */
+    /* crt_bvh_build_async: a device build on a stream and a host thread of its own, from a snapshot of the scene, into the
+     * spare blob; crt_bvh_swap makes it current */
+    std::thread build_thread; std::atomic<int> build_state{0};      /* 0 none, 1 running, 2 ready, 3 failed */
+    hipStream_t build_stream = nullptr; hipEvent_t ev_snap = nullptr, ev_build = nullptr;
+    void* d_blob2 = nullptr; size_t blob2_cap = 0;
+    crt_prim* d_prims_snap = nullptr; size_t snap_cap = 0;
+    DevBuild async_build{}; int async_rc = 0; std::string async_err;
     hipEvent_t refit_ev[2] = {nullptr, nullptr}; bool refit_pending = false;      /* ctx_refit_enqueue .. ctx_refit_finish */
     std::vector<uint32_t*> tl_ids; std::vector<int> tl_n; crt_params tl_key{};      /* per-rank tile lists for pack/unpack */
     crt_stats stats{};
 };
+
+/* an asynchronous rebuild that is running or waiting to be swapped in is abandoned (its thread joined) */
+static void cancel_async_build(crt_ctx* c) {
+    if (c->build_thread.joinable()) c->build_thread.join();
+    if (c->build_state.load() != 0) { c->d_blob2 = c->async_build.blob; c->blob2_cap = c->async_build.blob_cap; }      /* the build may have reallocated the spare blob */
+    c->build_state = 0;
+}
 
 namespace {
 
@@ -325,7 +347,6 @@ int ensure_frame(crt_ctx* c, FrameSlot& f, size_t cap, size_t npix, int bounces,
         int r;
         if ((r = realloc_exact(c, f.hitSlot, cap))) return r;
         if ((r = realloc_exact(c, f.hitT, cap))) return r;
-        if ((r = realloc_exact(c, f.rc, cap))) return r;
         f.cap = cap; f.nlights_alloc = 0;
     }
     const size_t nl = nlights > 0 ? (size_t)nlights : 1;
@@ -492,13 +513,17 @@ crt_ctx* crt_create(int device, int* err) {
 void crt_destroy(crt_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
+    cancel_async_build(c);
+    if (c->build_stream) { hipStreamSynchronize(c->build_stream); hipStreamDestroy(c->build_stream); }
+    if (c->ev_snap) hipEventDestroy(c->ev_snap);
+    if (c->ev_build) hipEventDestroy(c->ev_build);
     for (FrameSlot& f : c->fs) if (f.stream) hipStreamSynchronize(f.stream);
     hipStreamSynchronize(c->stream);
-    void* ptrs[] = {c->d_blob, c->d_prims, c->d_matid, c->d_arrive, c->d_status, c->d_testctr, c->d_ovf,
+    void* ptrs[] = {c->d_blob, c->d_blob2, c->d_prims_snap, c->d_prims, c->d_matid, c->d_arrive, c->d_status, c->d_testctr, c->d_ovf,
                     c->d_lbvh, c->d_lbvh_nodes, c->d_lbvh_s2s, c->d_area_table, c->d_refrank, c->d_refrank_out};
     for (void* p : ptrs) if (p) hipFree(p);
     for (FrameSlot& f : c->fs) {
-        void* fp[] = {f.rayO[0], f.rayO[1], f.rayD[0], f.rayD[1], f.coef[0], f.coef[1], f.pix[0], f.pix[1], f.hitSlot, f.hitT, f.rc,
+        void* fp[] = {f.rayO[0], f.rayO[1], f.rayD[0], f.rayD[1], f.coef[0], f.coef[1], f.pix[0], f.pix[1], f.hitSlot, f.hitT,
                       f.contrib, f.shO, f.shD, f.accum, f.sum, f.shflag, f.d_bgr, f.cap_ids, f.cap_ts, f.d_tiles, f.d_ctr,
                       f.d_sortkeys, f.d_sortperm, f.d_sorthist, f.d_sortkeys2, f.d_sortperm2};
         for (void* p : fp) if (p) hipFree(p);
@@ -538,6 +563,7 @@ int crt_scene_set(crt_ctx* c, const crt_prim* prims, int n) {
         if (prims[i].type != 0 && prims[i].type != 1) return fail(c, CRT_ERR_ARG, "crt_scene_set: type must be 0 (sphere) or 1 (triangle)");
     if (!finite_geometry(prims, n)) return fail(c, CRT_ERR_ARG, "crt_scene_set: non-finite coordinate");
     HIPCHECK(c, hipSetDevice(c->device));
+    cancel_async_build(c);
     { const int rc = drain_frames(c); if (rc) return rc; }
     c->prims.assign(prims, prims + n);
     dedupe_materials(c);
@@ -615,80 +641,100 @@ int crt_lights_set(crt_ctx* c, const crt_light* lights, int n) {
     return CRT_OK;
 }
 
-/* CRT_BVH_WIDE_DEVICE: lbvh.hip builds Node8 records from the device copy of the scene; the blob is laid out
- * once the node count is known, and from there on it is an ordinary wide-mode blob. */
-static int build_on_device(crt_ctx* c) {
+/* CRT_BVH_WIDE_DEVICE: lbvh.hip builds Node8 records from a device copy of the scene; the blob is laid out
+ * once the node count is known, and from there on it is an ordinary wide-mode blob.  One device build, described so
+ * that it can run on the context's stream into the current blob (crt_bvh_build) or on the build stream, from a snapshot
+ * of the scene, into the spare blob (crt_bvh_build_async: a host thread of its own, so it reports through `err`). */
+static int device_build_core(crt_ctx* c, DevBuild& B, std::string& err) {
+#define BHIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e_); return CRT_ERR_HIP; } } while (0)
     const uint32_t n = (uint32_t)c->prims.size();
     auto t0 = std::chrono::steady_clock::now();
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
-    const size_t need = lbvh_scratch_bytes(n);
-    if (need > c->lbvh_cap || !c->d_lbvh) {
-        if (c->d_lbvh) HIPCHECK(c, hipFree(c->d_lbvh));
-        c->d_lbvh = nullptr;
-        HIPCHECK(c, hipMalloc(&c->d_lbvh, need + need / 8));
-        c->lbvh_cap = need + need / 8;
-    }
+    auto grow = [&](void*& p, size_t& cap, size_t need) -> int {      /* byte-sized scratch that only grows */
+        if (need <= cap && p) return CRT_OK;
+        if (p) { BHIP(hipFree(p)); p = nullptr; cap = 0; }
+        BHIP(hipMalloc(&p, need + need / 8 + 256));
+        cap = need + need / 8 + 256;
+        return CRT_OK;
+    };
     int rc;
-    if ((rc = ensure(c, c->d_lbvh_nodes, c->lbvh_nodes_cap, (size_t)n))) return rc;
-    if ((rc = ensure(c, c->d_lbvh_s2s, c->lbvh_s2s_cap, (size_t)n))) return rc;
+    size_t cap_nodes = c->lbvh_nodes_cap * sizeof(Node8), cap_s2s = c->lbvh_s2s_cap * 4, cap_rout = c->refrank_out_cap * 4;
+    void *pn = c->d_lbvh_nodes, *ps = c->d_lbvh_s2s, *pr = c->d_refrank_out;
+    if ((rc = grow(c->d_lbvh, c->lbvh_cap, lbvh_scratch_bytes(n)))) return rc;
+    rc = grow(pn, cap_nodes, (size_t)n * sizeof(Node8)); c->d_lbvh_nodes = (Node8*)pn; c->lbvh_nodes_cap = cap_nodes / sizeof(Node8); if (rc) return rc;
+    rc = grow(ps, cap_s2s, (size_t)n * 4); c->d_lbvh_s2s = (uint32_t*)ps; c->lbvh_s2s_cap = cap_s2s / 4; if (rc) return rc;
     uint32_t nnodes = 0, depth = 0;
     float root_box[6];
-    std::string err;
-    rc = lbvh_build(c->d_lbvh, c->d_prims, n, c->d_lbvh_nodes, n, c->d_lbvh_s2s, &nnodes, &depth, root_box, c->stream, &err);
-    if (rc) return fail(c, rc, err.c_str());
+    rc = lbvh_build(c->d_lbvh, B.prims, n, c->d_lbvh_nodes, n, c->d_lbvh_s2s, &nnodes, &depth, root_box, B.s, &err);
+    if (rc) return rc;
     /* tie-break ranks: the reference's own leaf order, replayed on the device (refrank.hip).  Where its recursion does not
      * terminate (more than 64 primitives sharing a centroid coordinate on the split axis) ties resolve by scene index */
-    c->dev_rank_valid = false;
+    B.rank_valid = false;
     if (!getenv("CRT_DEVICE_BUILD_NO_REFRANK")) {
-        const size_t rneed = refrank_scratch_bytes(n);
-        if (rneed > c->refrank_cap || !c->d_refrank) {
-            if (c->d_refrank) HIPCHECK(c, hipFree(c->d_refrank));
-            c->d_refrank = nullptr;
-            HIPCHECK(c, hipMalloc(&c->d_refrank, rneed + rneed / 8));
-            c->refrank_cap = rneed + rneed / 8;
-        }
-        if ((rc = ensure(c, c->d_refrank_out, c->refrank_out_cap, (size_t)n))) return rc;
+        if ((rc = grow(c->d_refrank, c->refrank_cap, refrank_scratch_bytes(n)))) return rc;
+        rc = grow(pr, cap_rout, (size_t)n * 4); c->d_refrank_out = (uint32_t*)pr; c->refrank_out_cap = cap_rout / 4; if (rc) return rc;
         std::string rerr;
-        rc = refrank_build(c->d_refrank, c->d_prims, n, root_box, c->d_refrank_out, &c->refrank_levels, c->stream, &rerr);
-        if (rc == CRT_OK) c->dev_rank_valid = true;
-        else if (rc != CRT_ERR_BUILD) return fail(c, rc, rerr.c_str());
+        rc = refrank_build(c->d_refrank, B.prims, n, root_box, c->d_refrank_out, &B.levels, B.s, &rerr);
+        if (rc == CRT_OK) B.rank_valid = true;
+        else if (rc != CRT_ERR_BUILD) { err = rerr; return rc; }
     }
-
     BlobHeader h{};
     h.magic = kBlobMagic; h.version = kBlobVersion;
     h.nprims = n; h.nnodes = nnodes; h.nmats = (uint32_t)c->mats.size();
     h.depth = depth; h.mode = CRT_BVH_WIDE;
     memcpy(h.root_box, root_box, sizeof h.root_box);
     layout_blob(h);
-    if (h.total_bytes > c->blob_cap || !c->d_blob) {
-        if (c->d_blob) HIPCHECK(c, hipFree(c->d_blob));
-        c->d_blob = nullptr;
-        HIPCHECK(c, hipMalloc(&c->d_blob, h.total_bytes));
-        c->blob_cap = h.total_bytes;
+    if (h.total_bytes > B.blob_cap || !B.blob) {
+        if (B.blob) BHIP(hipFree(B.blob));
+        B.blob = nullptr; B.blob_cap = 0;
+        BHIP(hipMalloc(&B.blob, h.total_bytes + h.total_bytes / 16));      /* a little room: the next rebuild's tree differs by a few nodes */
+        B.blob_cap = h.total_bytes + h.total_bytes / 16;
     }
-    c->blob_bytes = h.total_bytes; c->hdr = h;
-    char* b = (char*)c->d_blob;
-    HIPCHECK(c, hipMemcpyAsync(b, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(b + h.off_nodes, c->d_lbvh_nodes, (size_t)nnodes * sizeof(Node8), hipMemcpyDeviceToDevice, c->stream));
-    launch_lbvh_maps(c->d_lbvh_s2s, c->dev_rank_valid ? c->d_refrank_out : nullptr, n, (uint32_t*)(b + h.off_sidx), (uint32_t*)(b + h.off_slot_of), (uint32_t*)(b + h.off_rank), c->stream);
-    if (h.nmats) HIPCHECK(c, hipMemcpyAsync(b + h.off_mats, c->mats.data(), (size_t)h.nmats * sizeof(Material), hipMemcpyHostToDevice, c->stream));
-    launch_pack_prims(c->d_prims, c->d_matid, (const uint32_t*)(b + h.off_slot_of), n, (Geom*)(b + h.off_geom), (Shade*)(b + h.off_shade), c->stream);
-    launch_quantize((const Node8*)(b + h.off_nodes), h.nnodes, (QNode8*)(b + h.off_qnodes), c->d_status, c->stream);
-    HIPCHECK(c, hipGetLastError());
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
-    rc = check_status(c);
+    B.hdr = h;
+    char* b = (char*)B.blob;
+    BHIP(hipMemcpyAsync(b, &B.hdr, sizeof h, hipMemcpyHostToDevice, B.s));
+    BHIP(hipMemcpyAsync(b + h.off_nodes, c->d_lbvh_nodes, (size_t)nnodes * sizeof(Node8), hipMemcpyDeviceToDevice, B.s));
+    launch_lbvh_maps(c->d_lbvh_s2s, B.rank_valid ? c->d_refrank_out : nullptr, n, (uint32_t*)(b + h.off_sidx), (uint32_t*)(b + h.off_slot_of), (uint32_t*)(b + h.off_rank), B.s);
+    if (h.nmats) BHIP(hipMemcpyAsync(b + h.off_mats, c->mats.data(), (size_t)h.nmats * sizeof(Material), hipMemcpyHostToDevice, B.s));
+    if (B.pack) {
+        launch_pack_prims(B.prims, c->d_matid, (const uint32_t*)(b + h.off_slot_of), n, (Geom*)(b + h.off_geom), (Shade*)(b + h.off_shade), B.s);
+        launch_quantize((const Node8*)(b + h.off_nodes), h.nnodes, (QNode8*)(b + h.off_qnodes), c->d_status, B.s);
+    }
+    BHIP(hipGetLastError());
+    BHIP(hipStreamSynchronize(B.s));
+    B.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return CRT_OK;
+#undef BHIP
+}
+
+/* what follows a device build on the context's own thread: arrival counters, pad scale, overflow rows, bookkeeping */
+static int adopt_device_tree(crt_ctx* c, const DevBuild& B) {
+    c->d_blob = B.blob; c->blob_cap = B.blob_cap; c->blob_bytes = B.hdr.total_bytes; c->hdr = B.hdr;
+    c->dev_rank_valid = B.rank_valid; c->refrank_levels = B.levels;
+    int rc = check_status(c);
     if (rc) return rc;
-    rc = ensure(c, c->d_arrive, c->arrive_cap, (size_t)h.nnodes + 1);
+    rc = ensure(c, c->d_arrive, c->arrive_cap, (size_t)B.hdr.nnodes + 1);
     if (rc) return rc;
     scene_abs_from_box(c);
     rc = size_overflow(c);
     if (rc) return rc;
     c->built = true; c->have_ref = false;
     c->ref = RefTree(); c->bvh = HostBVH();
-    c->stats.nodes = (int)h.nnodes; c->stats.prims = (int)n; c->stats.depth = (int)h.depth; c->stats.leaves = (int)n;
-    c->stats.scene_bytes = h.total_bytes;
-    c->stats.ms_build_device = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    const int n = (int)c->prims.size();
+    c->stats.nodes = (int)B.hdr.nnodes; c->stats.prims = n; c->stats.depth = (int)B.hdr.depth; c->stats.leaves = n;
+    c->stats.scene_bytes = B.hdr.total_bytes;
+    c->stats.ms_build_device = B.ms;
     return CRT_OK;
+}
+
+static int build_on_device(crt_ctx* c) {
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    DevBuild B{};
+    B.s = c->stream; B.prims = c->d_prims; B.pack = true; B.blob = c->d_blob; B.blob_cap = c->blob_cap;
+    std::string err;
+    const int rc = device_build_core(c, B, err);
+    c->d_blob = B.blob; c->blob_cap = B.blob_cap;          /* the core may have reallocated it even when it failed later */
+    if (rc) { c->built = false; return fail(c, rc, err.c_str()); }
+    return adopt_device_tree(c, B);
 }
 
 int crt_bvh_build(crt_ctx* c, int mode) {
@@ -696,6 +742,7 @@ int crt_bvh_build(crt_ctx* c, int mode) {
     if (mode != CRT_BVH_WIDE && mode != CRT_BVH_REFERENCE && mode != CRT_BVH_WIDE_DEVICE) return fail(c, CRT_ERR_ARG, "crt_bvh_build: unknown mode");
     if (c->imported) return fail(c, CRT_ERR_STATE, "crt_bvh_build: scene was imported as a blob");
     HIPCHECK(c, hipSetDevice(c->device));
+    cancel_async_build(c);
     { const int rc = drain_frames(c); if (rc) return rc; }      /* the blob may move: no frame may still be reading it */
     if (mode == CRT_BVH_WIDE_DEVICE) {
         if (!c->prims.empty()) return build_on_device(c);
@@ -772,6 +819,87 @@ int crt_bvh_build(crt_ctx* c, int mode) {
     return CRT_OK;
 }
 
+/* The rebuild of "rebuild every N frames" (main.cu:534-541) without the hitch: the device build runs on a stream and a host
+ * thread of its own, from a snapshot of the scene taken now (device-side, ordered behind whatever the context's stream has
+ * queued), into a spare blob, while frames keep rendering on the current tree (keep refitting it).  crt_bvh_swap makes the
+ * new tree current. */
+int crt_bvh_build_async(crt_ctx* c) {
+    if (!c) return CRT_ERR_ARG;
+    if (c->imported) return fail(c, CRT_ERR_STATE, "crt_bvh_build_async: scene was imported as a blob");
+    if (!c->built) return fail(c, CRT_ERR_STATE, "crt_bvh_build_async: no BVH yet (the first build is crt_bvh_build)");
+    if (c->prims.empty()) return fail(c, CRT_ERR_STATE, "crt_bvh_build_async: empty scene");
+    if (c->build_state.load() != 0) return fail(c, CRT_ERR_STATE, "crt_bvh_build_async: a rebuild is already under way (crt_bvh_swap collects it)");
+    HIPCHECK(c, hipSetDevice(c->device));
+    const size_t n = c->prims.size();
+    if (!c->build_stream) HIPCHECK(c, hipStreamCreateWithFlags(&c->build_stream, hipStreamNonBlocking));
+    if (!c->ev_snap) HIPCHECK(c, hipEventCreateWithFlags(&c->ev_snap, hipEventDisableTiming));
+    if (!c->ev_build) HIPCHECK(c, hipEventCreateWithFlags(&c->ev_build, hipEventDisableTiming));
+    int rc = ensure(c, c->d_prims_snap, c->snap_cap, n);
+    if (rc) return rc;
+    /* frames still reading the spare blob (it was the current one until the last swap) finish first */
+    for (int k = 0; k < CRT_MAX_FRAME_SLOTS; k++)
+        if (c->fs[k].in_flight) HIPCHECK(c, hipStreamWaitEvent(c->build_stream, c->fs[k].ev_done, 0));
+    /* the snapshot: behind the context's stream (the animation step just queued), and the context's stream behind it (the
+     * next animation step must not move the scene under the copy) */
+    HIPCHECK(c, hipEventRecord(c->ev_build, c->stream));
+    HIPCHECK(c, hipStreamWaitEvent(c->build_stream, c->ev_build, 0));
+    HIPCHECK(c, hipMemcpyAsync(c->d_prims_snap, c->d_prims, n * sizeof(crt_prim), hipMemcpyDeviceToDevice, c->build_stream));
+    HIPCHECK(c, hipEventRecord(c->ev_snap, c->build_stream));
+    HIPCHECK(c, hipStreamWaitEvent(c->stream, c->ev_snap, 0));
+    c->async_build = DevBuild{};
+    c->async_build.s = c->build_stream; c->async_build.prims = c->d_prims_snap; c->async_build.pack = false;
+    c->async_build.blob = c->d_blob2; c->async_build.blob_cap = c->blob2_cap;
+    c->async_err.clear(); c->async_rc = 0;
+    c->dev_rank_valid = false;          /* the rank buffer crt_bvh_reference_order reads is the builder's from here to the swap */
+    c->build_state = 1;
+    try {
+        c->build_thread = std::thread([c] {
+            (void)hipSetDevice(c->device);
+            c->async_rc = device_build_core(c, c->async_build, c->async_err);
+            c->build_state = c->async_rc ? 3 : 2;
+        });
+    } catch (const std::system_error&) {
+        c->build_state = 0;
+        return fail(c, CRT_ERR_NOMEM, "crt_bvh_build_async: cannot start the build thread");
+    }
+    return CRT_OK;
+}
+
+/* *swapped = 1 when the tree of the last crt_bvh_build_async became current: its geometry is packed from the scene as it
+ * is NOW and its boxes are refitted to it (the topology is the snapshot's), so the call replaces this frame's crt_bvh_refit.
+ * wait = 0 returns at once with *swapped = 0 while the build is still running. */
+int crt_bvh_swap(crt_ctx* c, int wait, int* swapped) {
+    if (!c) return CRT_ERR_ARG;
+    if (swapped) *swapped = 0;
+    const int st = c->build_state.load();
+    if (st == 0) return fail(c, CRT_ERR_STATE, "crt_bvh_swap: no crt_bvh_build_async under way");
+    if (st == 1 && !wait) return CRT_OK;
+    if (c->build_thread.joinable()) c->build_thread.join();
+    c->build_state = 0;
+    HIPCHECK(c, hipSetDevice(c->device));
+    DevBuild& B = c->async_build;
+    c->d_blob2 = B.blob; c->blob2_cap = B.blob_cap;          /* reallocated or not, the spare blob is this one now */
+    if (c->async_rc) return fail(c, c->async_rc, c->async_err.c_str());
+    /* pointers change hands: the old tree becomes the spare one and stays valid for the frames still in flight on it */
+    std::swap(c->d_blob, c->d_blob2); std::swap(c->blob_cap, c->blob2_cap);
+    B.blob = c->d_blob; B.blob_cap = c->blob_cap;
+    const int need_lds = stack_depth8_of(c->trace_block);
+    if ((int)B.hdr.depth + 2 > need_lds && (size_t)c->grid_blocks * kTraceBlock * (size_t)((int)B.hdr.depth + 2 - need_lds) * 2 * CRT_MAX_FRAME_SLOTS > c->ovf_cap) {
+        const int rc = drain_frames(c);          /* the overflow rows are about to move */
+        if (rc) return rc;
+    }
+    int rc = adopt_device_tree(c, B);
+    if (rc) return rc;
+    char* b = (char*)c->d_blob;
+    const uint32_t n = (uint32_t)c->prims.size();
+    launch_pack_prims(c->d_prims, c->d_matid, (const uint32_t*)(b + c->hdr.off_slot_of), n, (Geom*)(b + c->hdr.off_geom), (Shade*)(b + c->hdr.off_shade), c->stream);
+    HIPCHECK(c, hipGetLastError());
+    rc = crt_bvh_refit(c, CRT_REFIT_TIGHT);      /* boxes of the snapshot's topology around today's positions, then the quantised nodes */
+    if (rc) return rc;
+    if (swapped) *swapped = 1;
+    return CRT_OK;
+}
+
 int crt_bvh_refit(crt_ctx* c, int grow_only) {
     const int rc = crt::ctx_refit_enqueue(c, grow_only);
     return rc ? rc : crt::ctx_refit_finish(c);
@@ -780,6 +908,7 @@ int crt_bvh_refit(crt_ctx* c, int grow_only) {
 int crt_bvh_free(crt_ctx* c) {
     if (!c) return CRT_ERR_ARG;
     HIPCHECK(c, hipSetDevice(c->device));
+    cancel_async_build(c);
     { const int rc = drain_frames(c); if (rc) return rc; }
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     if (c->d_blob) { HIPCHECK(c, hipFree(c->d_blob)); c->d_blob = nullptr; }
@@ -971,14 +1100,18 @@ int crt_render_submit(crt_ctx* c, int slot, const crt_camera* cam, const crt_par
     if (gb < 1) gb = 1;
     uint32_t* const ovf = c->d_ovf + (size_t)slot * c->ovf_slot_words;
     if (p->use_graph) { int e = 0; (void)frexpf(sabs > 0.f ? sabs : 1.f, &e); sabs = ldexpf(1.0f, e); }
+    /* per-ray shadow directions are stored only where they differ from ray to ray (point lights, area samples) or where the
+     * traversal kernel has no light table (the reference topology's k_trace) */
+    bool need_shD = c->hdr.mode != CRT_BVH_WIDE;
+    for (int j = 0; j < lights.n; j++) need_shD = need_shD || lights.l[j].area || lights.l[j].point;
     auto enqueue = [&]() {
     for (int s = 0; s < spp; s++) {
         uint32_t* ctr = f.d_ctr + (size_t)s * kCtrStride;
         fp.sample = s;
         int cur = 0;
         FrameBuffers fb{};
-        fb.hitSlot = f.hitSlot; fb.hitT = f.hitT; fb.rc = f.rc; fb.contrib = f.contrib; fb.shflag = f.shflag;
-        fb.shO = f.shO; fb.shD = f.shD; fb.area_table = c->d_area_table; fb.accum = f.accum; fb.cap_ids = f.cap_ids; fb.cap_ts = f.cap_ts;
+        fb.hitSlot = f.hitSlot; fb.hitT = f.hitT; fb.contrib = f.contrib; fb.shflag = f.shflag;
+        fb.shO = f.shO; fb.shD = need_shD ? f.shD : nullptr; fb.area_table = c->d_area_table; fb.accum = f.accum; fb.cap_ids = f.cap_ids; fb.cap_ts = f.cap_ts;
         fb.cap = (uint32_t)f.cap; fb.cap_stride = (uint32_t)npix; fb.tile_ids = f.d_tiles;
         auto bind = [&](int k) {
             fb.rayO = f.rayO[k]; fb.rayD = f.rayD[k]; fb.coef = f.coef[k]; fb.pix = f.pix[k];
@@ -1015,7 +1148,11 @@ int crt_render_submit(crt_ctx* c, int slot, const crt_camera* cam, const crt_par
                 common(tm, 2 * b + 1);
                 const bool has_sh = c->lights.n > 0, has_nx = b + 1 < p->bounces;
                 if (has_sh) {
-                    tm.shO = f.shO; tm.shD = f.shD; tm.shcount = ctr + 16 + b;
+                    tm.shO = f.shO; tm.shD = fb.shD; tm.shcount = ctr + 16 + b;
+                    if (!fb.shD) {          /* directions by light slot: every light is directional */
+                        tm.sh_cap = (uint32_t)f.cap; tm.sh_nslots = (uint32_t)lights.nslots;
+                        for (int j = 0; j < lights.n; j++) { memcpy(tm.sh_dir[j], lights.l[j].direction, 12); tm.sh_dir[j][3] = 0.f; }      /* normalised on the device, as k_shade does */
+                    }
                     if (p->sort_rays) {
                         launch_sort_rays(f.shO, ctr + 16 + b, (uint32_t)(f.cap * (size_t)lights.nslots), d_root_box, f.d_sortkeys, f.d_sorthist,
                                          f.d_sortperm, f.stream);
@@ -1043,7 +1180,7 @@ int crt_render_submit(crt_ctx* c, int slot, const crt_camera* cam, const crt_par
                 launch_trace(ts, TRACE_SHADOW, c->counting, false, gb, f.stream);
                 mark(f, EV_TRACE_S);
             }
-            launch_resolve(fb, lights, ctr + b, f.stream);
+            launch_resolve(fb, lights, ctr + b, b, f.stream);
             mark(f, EV_RESOLVE);
             cur ^= 1;
         }
@@ -1064,7 +1201,7 @@ int crt_render_submit(crt_ctx* c, int slot, const crt_camera* cam, const crt_par
         key.cam = *cam; key.p = *p; key.lights = lights;
         /* everything a captured launch bakes in: every buffer (size_overflow() may move d_ovf and change ovf_depth on any
          * rebuild or import that leaves the blob's address and counts as they were), every header field the offsets derive from */
-        const void* ptrs[20] = {c->d_blob, f.rayO[0], f.rayO[1], f.hitSlot, f.rc, f.contrib, f.shO, f.accum, f.d_ctr, dev_bgr,
+        const void* ptrs[20] = {c->d_blob, f.rayO[0], f.rayO[1], f.hitSlot, f.hitT, f.contrib, f.shO, f.accum, f.d_ctr, dev_bgr,
                                 f.d_tiles, f.cap_ids, c->d_ovf, f.d_sortkeys, f.d_sortperm, f.d_sortkeys2, f.d_sortperm2, f.d_sorthist,
                                 c->d_area_table, f.sum};
         memcpy(key.ptrs, ptrs, sizeof ptrs);
@@ -1359,6 +1496,7 @@ int crt_blob_device_ptr(crt_ctx* c, void** p) {
 int crt_blob_import_device(crt_ctx* c, const void* dev_ptr, size_t bytes) {
     if (!c || !dev_ptr || bytes < sizeof(BlobHeader)) return fail(c, CRT_ERR_ARG, "crt_blob_import_device: bad arguments");
     HIPCHECK(c, hipSetDevice(c->device));
+    cancel_async_build(c);
     { const int rc = drain_frames(c); if (rc) return rc; }
     BlobHeader h;
     HIPCHECK(c, hipMemcpy(&h, dev_ptr, sizeof h, hipMemcpyDeviceToHost));

@@ -93,6 +93,10 @@ struct LightsParam {
  *   +dtoLight (sign 0)    point light: nearest hit, shadowed iff dtoLight > |t * dir| (Ray.cu:621-629)
  *   -dtoLight (sign 1)    area-light sample: as the point light, and only if the nearest t > 1e-9 (Ray.cu:587-596) */
 constexpr uint32_t kShadowDirectional = 0xff800000u;
+/* shflag[slot * cap + i], one byte per path and light slot: 0 lit so far (a traversal may set 1), 1 shadowed (the record in
+ * contrib still counts: distance * 0, Ray.cu:629,655), and two values only k_shade writes: */
+constexpr uint8_t kShDeadPath = 2;          /* the path hit neither object nor wall: it ended, nothing is added (all slots carry it) */
+constexpr uint8_t kShNoContribution = 3;    /* shadowed without a ray and the term is finite: adds an exact zero, contrib not written */
 
 /* Area lights (commented out in the reference, Ray.cu:563-603): sample k of a shading point
  * takes entry (h + k) mod kAreaTable of a table of unit-disk samples (u, cos(theta), sin(theta)) built on the
@@ -111,9 +115,9 @@ struct FrameBuffers {
     float4* rayO; float4* rayD; float4* coef; uint32_t* pix;           /* current queue */
     float4* nrayO; float4* nrayD; float4* ncoef; uint32_t* npix;       /* next-bounce queue */
     int32_t* hitSlot; float* hitT;
-    float4* rc; float4* contrib; uint8_t* shflag;
+    float4* contrib; uint8_t* shflag;
     const float4* area_table;                                          /* kAreaTable entries (u, cos, sin, 0) */
-    float4* shO; float4* shD;                                          /* shadow-ray queue: .w = target / light */
+    float4* shO; float4* shD;                                          /* shadow-ray queue: .w = target / light; shD null when every light is directional (k_trace8 takes the direction from the slot) */
     float4* accum;                                                     /* per pixel float colour (isect.color) */
     int32_t* cap_ids; float* cap_ts;                                   /* capture planes [bounce][pixel] or null */
     uint32_t cap;                                                      /* queue capacity: stride of the per-light planes */
@@ -131,6 +135,10 @@ struct TraceArgs {
     const float4* shO; const float4* shD;    /* k_trace8 only: the shadow queue served by the same launch, */
     const uint32_t* shcount;                 /* null = none (k_trace takes its one queue in rayO/rayD/count) */
     const uint32_t* shperm;
+    /* shD null: the queue carries no directions.  Light slot of a ray = plane number of its target = target / sh_cap;
+     * sh_dir[slot] = crt_light.direction of that (directional) light, sh_nslots of them */
+    uint32_t sh_cap, sh_nslots;
+    float sh_dir[CRT_MAX_LIGHTS][4];
     uint32_t* next;              /* 8 fetch counters, kFetchStride words apart (device, zeroed) */
     int32_t* hitSlot; float* hitT;           /* NEAREST outputs */
     uint8_t* shflag;                         /* SHADOW output, indexed by the target in rayO.w */
@@ -150,7 +158,7 @@ void launch_quantize(const Node8* nodes, uint32_t nnodes, QNode8* qnodes, uint32
 void launch_gen_primary(const FrameParams& fp, const FrameBuffers& fb, uint32_t* count, hipStream_t s);
 void launch_shade(const FrameParams& fp, const FrameBuffers& fb, const SceneView& sv, const LightsParam& lights,
                   const uint32_t* count, uint32_t* next_count, uint32_t* shadow_count, hipStream_t s);
-void launch_resolve(const FrameBuffers& fb, const LightsParam& lights, const uint32_t* count, hipStream_t s);
+void launch_resolve(const FrameBuffers& fb, const LightsParam& lights, const uint32_t* count, int bounce, hipStream_t s);
 void launch_convert(const FrameParams& fp, const FrameBuffers& fb, const float4* sum_or_null, uint8_t* bgr, hipStream_t s);
 void launch_spp_accumulate(const FrameParams& fp, const FrameBuffers& fb, float4* sum, hipStream_t s);
 /* optional ray sorting (crt_params.sort_rays): visiting order of a ray queue by the Morton code of the

@@ -460,6 +460,8 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
     __shared__ uint32_t s_cnt[BLOCK];                /* lanes still working on the ray */
     __shared__ uint32_t s_best[BLOCK];               /* slot that holds the minimum */
     __shared__ uint8_t s_pair[BLOCK];                /* steal step: the wave's offering lanes, compacted */
+    /* shadow queue without per-ray directions (A.shD null: every light is directional): unit vector towards light slot k */
+    __shared__ float4 s_ldir[CRT_MAX_LIGHTS];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wbase = tid & ~63;
@@ -468,6 +470,10 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
         int y = 0;
         for (int k = 0; k < 8; k++) if ((m >> k) & 1) y |= 1 << (k ^ R_);
         s_perm[R_][m] = (uint8_t)y;
+    }
+    if (tid < CRT_MAX_LIGHTS && !A.shD && tid < (int)A.sh_nslots) {          /* toLight of Ray.cu:634, evaluated as k_shade evaluates it */
+        const vec3 tl = -normalize(vec3(A.sh_dir[tid][0], A.sh_dir[tid][1], A.sh_dir[tid][2]));
+        s_ldir[tid] = make_float4(tl.x, tl.y, tl.z, 0.f);
     }
     __syncthreads();
     /* one launch serves TWO independent queues: the shadow rays of a bounce and the nearest-hit rays of the
@@ -623,7 +629,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                     if (mine) {          /* issue the loads only: they complete under the traversal step below */
                         if (sh) {
                             const uint32_t q = A.shperm ? A.shperm[idx] : idx;      /* sorted visiting order, if any */
-                            pro4 = A.shO[q]; prd = A.shD[q]; ray = q | 0x80000000u;
+                            pro4 = A.shO[q]; if (A.shD) prd = A.shD[q]; ray = q | 0x80000000u;
                         } else {
                             const uint32_t q = A.perm ? A.perm[idx - ns64] : idx - ns64;
                             pro4 = A.rayO[q]; prd = A.rayD[q]; ray = q;
@@ -864,7 +870,18 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
             } else {
                 ray = idx;
                 o = vec3(ro.x, ro.y, ro.z); d = vec3(rd.x, rd.y, rd.z);
-                if (shray) { ray = __float_as_uint(ro.w) | 0x80000000u; lkind = __float_as_uint(rd.w); }
+                if (shray) {
+                    const uint32_t plane = __float_as_uint(ro.w);
+                    ray = plane | 0x80000000u; lkind = __float_as_uint(rd.w);
+                    if (!A.shD) {
+                        /* the queue holds (origin, target) only: the target's plane number is the light slot, and with nothing
+                         * but directional lights a slot is a light (k_shade wrote no direction: 16 B per ray less each way) */
+                        uint32_t slot = 0;
+                        for (uint32_t k = 1; k < A.sh_nslots; k++) slot += plane >= k * A.sh_cap ? 1u : 0u;
+                        const float4 ld = s_ldir[slot];
+                        d = vec3(ld.x, ld.y, ld.z); lkind = kShadowDirectional;
+                    }
+                }
                 /* v_rcp_f32 (1 ulp) instead of an IEEE division: the box test only has to be
                  * conservative and the pad below is 1e4 times that error */
                 float rx = __builtin_amdgcn_rcpf(d.x), ry = __builtin_amdgcn_rcpf(d.y), rz = __builtin_amdgcn_rcpf(d.z);
@@ -1167,6 +1184,22 @@ CRT_DEV uint32_t queue_slot(bool want, uint32_t* counter) {
  * k_gen_primary: GeneratePrimaryRays (Ray.cu:31-52).  Path q of this rank -> tile -> 8x8 pixel
  * block per wave.  The reference's literal 720 (Ray.cu:37-38) becomes `width`.
  * ------------------------------------------------------------------------------------------ */
+/* Ray.cu:39-47 for pixel (px, py): shared by k_gen_primary and by k_shade, which recomputes the primary ray of a path from
+ * its pixel instead of reading it back (same expressions, same order, no contraction: the same bits) */
+CRT_DEV vec3 primary_direction(const FrameParams& P, int px, int py) {
+    const vec3 L(P.L), u(P.u), v(P.v), cam(P.cam);
+    vec3 pix;
+    if (P.spp_n <= 1) {
+        pix = (L + u * float(px) + v * float(py));
+    } else {        /* stratified sub-pixel offsets along u and v: an extension, SURVEY.md 8(d) config 5 */
+        const float ox = ((float)(P.sample % P.spp_n) + .5f) / (float)P.spp_n - .5f;
+        const float oy = ((float)(P.sample / P.spp_n) + .5f) / (float)P.spp_n - .5f;
+        pix = (L + u * (float(px) + ox) + v * (float(py) + oy));
+    }
+    const float xoffset = 0, yoffset = 0;
+    return normalize(vec3(pix.x + xoffset, pix.y + yoffset, pix.z) - cam);
+}
+
 __global__ __launch_bounds__(256) void k_gen_primary(FrameParams P, FrameBuffers B, uint32_t* count) {
     const uint32_t per_tile = (uint32_t)(P.tile_w * P.tile_h);
     const uint32_t total = (uint32_t)P.ntiles_owned * per_tile;
@@ -1187,17 +1220,8 @@ __global__ __launch_bounds__(256) void k_gen_primary(FrameParams P, FrameBuffers
             B.pix[q] = 0xffffffffu;
             continue;
         }
-        const vec3 L(P.L), u(P.u), v(P.v), cam(P.cam);
-        vec3 pix;
-        if (P.spp_n <= 1) {
-            pix = (L + u * float(px) + v * float(py));
-        } else {        /* stratified sub-pixel offsets along u and v: an extension, SURVEY.md 8(d) config 5 */
-            const float ox = ((float)(P.sample % P.spp_n) + .5f) / (float)P.spp_n - .5f;
-            const float oy = ((float)(P.sample / P.spp_n) + .5f) / (float)P.spp_n - .5f;
-            pix = (L + u * (float(px) + ox) + v * (float(py) + oy));
-        }
-        const float xoffset = 0, yoffset = 0;
-        const vec3 sample = normalize(vec3(pix.x + xoffset, pix.y + yoffset, pix.z) - cam);
+        const vec3 cam(P.cam);
+        const vec3 sample = primary_direction(P, px, py);
         B.rayO[q] = make_float4(cam.x, cam.y, cam.z, 0.f);
         B.rayD[q] = make_float4(sample.x, sample.y, sample.z, 0.f);
         B.pix[q] = (uint32_t)(py * P.width + px);
@@ -1370,17 +1394,23 @@ __global__ CRT_SHADE_BOUNDS void k_shade(FrameParams P, FrameBuffers B, SceneVie
     const int raytype = P.bounce > 0 ? 1 : 0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += stride) {
-        const bool valid = i < total && B.hitSlot[i] != -3;      /* -3: hole left by a clipped tile */
-        if (i < total && !valid) B.rc[i] = make_float4(0.f, 0.f, 0.f, 0.f);   /* k_resolve skips w == 0 */
+        const int slot_i = i < total ? B.hitSlot[i] : -3;
+        const bool valid = slot_i != -3;                        /* -3: hole left by a clipped tile (k_resolve skips it by its pixel) */
         bool dead = !valid;
         vec3 o, d, cin, P_, N, incident, rc, newcoef, diffuse, specular;
         float shininess = 0.f;
         uint32_t pix = 0;
         if (valid) {
-            const float4 ro = B.rayO[i], rd = B.rayD[i], ci = B.coef[i];
-            o = vec3(ro.x, ro.y, ro.z); d = vec3(rd.x, rd.y, rd.z); cin = vec3(ci.x, ci.y, ci.z);
             pix = B.pix[i];
-            const int slot = B.hitSlot[i];
+            if (raytype == 0) {
+                /* a primary ray is a function of its pixel (Ray.cu:31-52): recomputed, not read back -- 48 B per path less */
+                o = vec3(P.cam);
+                d = primary_direction(P, (int)(pix % (uint32_t)P.width), (int)(pix / (uint32_t)P.width));
+            } else {
+                const float4 ro = B.rayO[i], rd = B.rayD[i], ci = B.coef[i];
+                o = vec3(ro.x, ro.y, ro.z); d = vec3(rd.x, rd.y, rd.z); cin = vec3(ci.x, ci.y, ci.z);
+            }
+            const int slot = slot_i;
             int cap_id = -1;
             if (slot >= 0) {
                 /* RayIntersection hit branch, Ray.cu:479-511, with the full intersect functions */
@@ -1460,7 +1490,6 @@ __global__ CRT_SHADE_BOUNDS void k_shade(FrameParams P, FrameBuffers B, SceneVie
                 B.cap_ids[(size_t)P.bounce * B.cap_stride + pix] = cap_id;
                 B.cap_ts[(size_t)P.bounce * B.cap_stride + pix] = B.hitT[i];
             }
-            B.rc[i] = make_float4(rc.x, rc.y, rc.z, dead ? 0.f : 1.f);
         }
 
         /* ---- reserve queue space: count this block's shadow and reflection rays ---- */
@@ -1538,14 +1567,17 @@ __global__ CRT_SHADE_BOUNDS void k_shade(FrameParams P, FrameBuffers B, SceneVie
                     const float sdot = dot(reflect(reflectFromLight, N), -direction);
                                         const float spec = powf_libm(sdot, shininess, s_ltab, s_etab);
                     const vec3 X = (.6f * diffuse * gmax(dot(toLight, N), 0.0f) + .2f * specular * spec);
-                    B.contrib[plane] = make_float4(X.x, X.y, X.z, distance);
+                    /* a light that is shadowed without a ray contributes distance * 0 * lcolor * X (Ray.cu:629,655): exactly zero
+                     * unless X is not finite, so the 16-byte record is written only where Ray.cu:660 can see it */
+                    if (flag && X.x - X.x == 0.f && X.y - X.y == 0.f && X.z - X.z == 0.f) flag = kShNoContribution;
+                    else B.contrib[plane] = make_float4(X.x, X.y, X.z, distance);
                     B.shflag[plane] = flag;
-                }
+                } else if (valid) B.shflag[plane] = kShDeadPath;
                 const unsigned long long wm = crt_ballot(want);
                 if (want) {
                     const uint32_t ks = sh_run + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull));
                     B.shO[ks] = make_float4(sorg.x, sorg.y, sorg.z, __uint_as_float((uint32_t)plane));
-                    B.shD[ks] = make_float4(toLight.x, toLight.y, toLight.z, __uint_as_float(lbits));
+                    if (B.shD) B.shD[ks] = make_float4(toLight.x, toLight.y, toLight.z, __uint_as_float(lbits));
                 }
                 sh_run += (uint32_t)__popcll(wm);
             }
@@ -1568,52 +1600,61 @@ void launch_shade(const FrameParams& fp, const FrameBuffers& fb, const SceneView
                   const uint32_t* count, uint32_t* next_count, uint32_t* shadow_count, hipStream_t s) {
     /* grid-stride over the queue; no more blocks than the queue can have entries */
     uint32_t blocks = (fb.cap + 255u) / 256u;
-    blocks = blocks < 1u ? 1u : (blocks > 4096u ? 4096u : blocks);
+    static const uint32_t maxb = [] { const char* v = getenv("CRT_SHADE_BLOCKS"); return v ? (uint32_t)atoi(v) : 4096u; }();
+    blocks = blocks < 1u ? 1u : (blocks > maxb ? maxb : blocks);
     hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, s, fp, fb, sv, lights, count, next_count, shadow_count);
 }
 
 /* isectPoints[i].color += reflectionCoef * color (Ray.cu:660), colour summed over lights in order
  * with `distance * 0` for shadowed lights (Ray.cu:629,655) */
-__global__ __launch_bounds__(256) void k_resolve(FrameBuffers B, LightsParam LP, const uint32_t* count) {
+__global__ __launch_bounds__(256) void k_resolve(FrameBuffers B, LightsParam LP, const uint32_t* count, int bounce) {
     const uint32_t total = *count;
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const float4 rc4 = B.rc[i];
-        if (rc4.w == 0.f) continue;
+        const uint32_t pix = B.pix[i];
+        if (pix == 0xffffffffu) continue;              /* hole left by a clipped tile */
         vec3 color;
+        bool deadpath = false;
         for (int j = 0; j < LP.n; j++) {
             const vec3 lcolor(LP.l[j].color);
             if (LP.l[j].area) {                       /* Ray.cu:565-601: mean over the samples */
                 vec3 avgcolor;
                 for (int k = 0; k < LP.area_samples; k++) {
                     const size_t plane = (size_t)(LP.slot_base[j] + k) * B.cap + i;
+                    const uint8_t fl = B.shflag[plane];
+                    if (fl == kShDeadPath) { deadpath = true; break; }
                     const float4 c = B.contrib[plane];
                     float distance = c.w;
-                    if (B.shflag[plane]) distance = distance * 0;
+                    if (fl) distance = distance * 0;
                     avgcolor += distance * lcolor * vec3(c.x, c.y, c.z);
                 }
                 color += avgcolor / (float)LP.area_samples;
             } else {
                 const size_t plane = (size_t)LP.slot_base[j] * B.cap + i;
+                const uint8_t fl = B.shflag[plane];
+                if (fl == kShDeadPath) { deadpath = true; break; }
+                if (fl == kShNoContribution) continue;            /* adds an exact zero */
                 const float4 c = B.contrib[plane];
                 float distance = c.w;
-                if (B.shflag[plane]) distance = distance * 0;
+                if (fl) distance = distance * 0;
                 color += distance * lcolor * vec3(c.x, c.y, c.z);
             }
         }
-        const uint32_t pix = B.pix[i];
-        if (pix == 0xffffffffu) continue;
+        if (deadpath) continue;                        /* neither object nor wall: the path ended, colour unchanged */
+        /* isect.reflectionCoef: 1 for a primary hit, the running product carried by the ray otherwise (Ray.cu:482-491) */
+        vec3 rc(1.0f, 1.0f, 1.0f);
+        if (bounce > 0) { const float4 ci = B.coef[i]; rc = vec3(ci.x, ci.y, ci.z); }
         float4 a = B.accum[pix];
         vec3 acc(a.x, a.y, a.z);
-        acc += vec3(rc4.x, rc4.y, rc4.z) * color;
+        acc += rc * color;
         B.accum[pix] = make_float4(acc.x, acc.y, acc.z, 0.f);
     }
 }
 
-void launch_resolve(const FrameBuffers& fb, const LightsParam& lights, const uint32_t* count, hipStream_t s) {
+void launch_resolve(const FrameBuffers& fb, const LightsParam& lights, const uint32_t* count, int bounce, hipStream_t s) {
     uint32_t blocks = (fb.cap + 255u) / 256u;
     blocks = blocks < 1u ? 1u : (blocks > 4096u ? 4096u : blocks);
-    hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, s, fb, lights, count);
+    hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, s, fb, lights, count, bounce);
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -158,6 +158,18 @@ int crt_scene_get(crt_ctx*, crt_prim* prims_out, int n);        /* current scene
                               * animated scenes.  Builds from the device copy of the scene (after crt_animate_device no
                               * copy back); no reference-order pass: exact-t ties resolve by scene index */
 int crt_bvh_build(crt_ctx*, int mode);
+/* "Rebuild every N frames" (main.cu:534-541) without the stall of a synchronous rebuild; no counterpart in the reference,
+ * whose loop stops for its host build.  crt_bvh_build_async starts a CRT_BVH_WIDE_DEVICE build on a stream and a host
+ * thread of its own, from a snapshot of the scene as the context's stream leaves it (take it right after the frame's
+ * crt_animate_device), into a spare blob, and returns; frames keep rendering on the current tree (keep refitting it).
+ * crt_bvh_swap(ctx, wait, &swapped): once the build is done (wait != 0: wait for it) the new tree becomes current -- its
+ * geometry packed from the scene as it is now, its boxes refitted to it, so the call stands in for that frame's
+ * crt_bvh_refit -- and *swapped = 1.  Tie-break ranks are those of the snapshot, as a synchronous rebuild at the snapshot's
+ * frame would have produced; frames rendered between the snapshot and the swap still use the previous build's ranks (only
+ * exact-t ties between duplicated primitives can tell).  One build at a time; crt_bvh_build / crt_scene_set / crt_bvh_free /
+ * crt_blob_import_device abandon a build under way. */
+int crt_bvh_build_async(crt_ctx*);
+int crt_bvh_swap(crt_ctx*, int wait, int* swapped);
 #define CRT_REFIT_TIGHT 0
 #define CRT_REFIT_GROW 1     /* boxes only grow, as refitTree does */
 int crt_bvh_refit(crt_ctx*, int grow_only);

@@ -4,7 +4,10 @@
  * algorithm description line by line; every function cites the reference file:line it follows.
  * Arithmetic is IEEE binary32 with the reference's operation order (see ovec.h); where the
  * reference's C++ promotes a comparison to double the promotion is kept.  `pow(float,int)` and
- * `sqrt(float)` are evaluated in float, which is what the CUDA device build of the reference does.
+ * `sqrt(float)` are evaluated in float, which is what the CUDA device build of the reference does
+ * (the parity target of the kernels).  -DORC_HOST_POW builds the other reading (liboracle_hostpow.so):
+ * std::pow(float,int) and sqrt of its sum in double, as a HOST build of Ray.cu:110,592-593,606-607,626-627
+ * evaluates them; tests/test_oracle_hostpow.py measures how far the two are apart.
  *
  * PARITY STATUS: "parity unpinned" for the render logic (Ray.cu, bvh.cu cannot be compiled here
  * without stand-ins for CUDA and the reference ships no tests/golden vectors); vec3 math and the
@@ -32,6 +35,19 @@
 #include <string>
 
 namespace {
+
+/* the three expressions of the reference that call pow(float, 2) (and sqrt of a sum of them) */
+#ifdef ORC_HOST_POW
+/* host build: pow promotes to double -- x^2 is exact there -- the sum and the square root are double, the assignment rounds once */
+inline float sub_r2(float sum, float r) { return (float)((double)sum - (double)r * (double)r); }                                    /* Ray.cu:110 */
+inline float len3(float a, float b, float c) { return (float)sqrt(((double)a * (double)a + (double)b * (double)b) + (double)c * (double)c); }   /* Ray.cu:592-593,606,626-627 */
+inline float attenuation(float ct, float lt, float qt, float d) { return (float)(1.0f / ((double)(ct + lt * d) + (double)qt * ((double)d * (double)d))); }   /* Ray.cu:607 */
+#else
+/* CUDA device build: pow(float, int) and sqrt(float) stay in float */
+inline float sub_r2(float sum, float r) { return sum - r * r; }
+inline float len3(float a, float b, float c) { return sqrtf(a * a + b * b + c * c); }
+inline float attenuation(float ct, float lt, float qt, float d) { return 1.0f / (ct + lt * d + qt * (d * d)); }
+#endif
 
 struct Counters {
     uint64_t traversals = 0, primary = 0, shadow = 0, reflect = 0;
@@ -103,7 +119,7 @@ bool sphere_hit(const orc_prim& s, const ov3& position, const ov3& direction, fl
     ov3 spos(s.position);
     float a = odot(direction, direction);
     float b = 2 * odot(direction, position - spos);
-    float c = odot(spos, spos) + odot(position, position) + (-2 * odot(spos, position)) - s.radius * s.radius;
+    float c = sub_r2(odot(spos, spos) + odot(position, position) + (-2 * odot(spos, position)), s.radius);
     float discriminant = b * b - 4 * a * c;
     if ((double)discriminant > 0.0 + (double)RAY_EPSILON) {
         float t = (-b - sqrtf(discriminant)) / (2 * a);
@@ -371,9 +387,9 @@ void shade(const orc_scene* sc, IsectS& is, const orc_light* lights, int numligh
                     if (minT > RAY_EPSILON) {
                         ov3 ipoint = intersection + minT * toLight;
                         float ax = intersection.x - spos.x, ay = intersection.y - spos.y, az = intersection.z - spos.z;
-                        float dtoLight = sqrtf(ax * ax + ay * ay + az * az);
+                        float dtoLight = len3(ax, ay, az);
                         float bx = ipoint.x - intersection.x, by = ipoint.y - intersection.y, bz = ipoint.z - intersection.z;
-                        float dtoLightIntersection = sqrtf(bx * bx + by * by + bz * bz);
+                        float dtoLightIntersection = len3(bx, by, bz);
                         if (dtoLight > dtoLightIntersection) distance = distance * 0;
                     }
                 }
@@ -383,8 +399,8 @@ void shade(const orc_scene* sc, IsectS& is, const orc_light* lights, int numligh
             color += avgcolor / (float)lightSamples;
         } else if (l.point) {
             float dx = intersection.x - lpos.x, dy = intersection.y - lpos.y, dz = intersection.z - lpos.z;
-            float d = sqrtf(dx * dx + dy * dy + dz * dz);
-            distance = 1.0f / (l.constantTerm + l.linearTerm * d + l.quadraticTerm * (d * d));
+            float d = len3(dx, dy, dz);
+            distance = attenuation(l.constantTerm, l.linearTerm, l.quadraticTerm, d);
             if (distance > 1.5) distance = .5;
             toLight = onormalize(lpos - intersection);
             reflectFromLight = -toLight;
@@ -395,9 +411,9 @@ void shade(const orc_scene* sc, IsectS& is, const orc_light* lights, int numligh
             if (shadow) {
                 ov3 ipoint = intersection + minT * toLight;
                 float ax = intersection.x - lpos.x, ay = intersection.y - lpos.y, az = intersection.z - lpos.z;
-                float dtoLight = sqrtf(ax * ax + ay * ay + az * az);
+                float dtoLight = len3(ax, ay, az);
                 float bx = ipoint.x - intersection.x, by = ipoint.y - intersection.y, bz = ipoint.z - intersection.z;
-                float dtoLightIntersection = sqrtf(bx * bx + by * by + bz * bz);
+                float dtoLightIntersection = len3(bx, by, bz);
                 if (dtoLight > dtoLightIntersection) distance = distance * 0;
             }
             color += distance * lcol * (.6f * is.diffuse * omax(odot(toLight, normal), 0.0f) +

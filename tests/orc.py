@@ -8,7 +8,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+# ORC_VARIANT=hostpow: the restatement with pow(float,int)/sqrt in double (a host build's rounding), tests/test_oracle_hostpow.py
+VARIANT = os.environ.get("ORC_VARIANT", "")
+LIB = os.path.join(ORACLE_DIR, "liboracle_hostpow.so" if VARIANT == "hostpow" else "liboracle.so")
 REF_DRIVER = os.path.join(ORACLE_DIR, "_ref", "ref_driver")
 
 PRIM_DTYPE = np.dtype([
@@ -37,7 +39,7 @@ class Stats(C.Structure):
 
 def build():
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(ORACLE_DIR, "crt_oracle.cpp")):
-        subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", ORACLE_DIR, os.path.basename(LIB)], stdout=subprocess.DEVNULL)
 
 
 _lib = None

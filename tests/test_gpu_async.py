@@ -138,3 +138,49 @@ def test_animation_is_ordered_between_frames_in_flight():
         for q in ptrs:
             hip.hipFree(C.c_void_p(q))
         ctx.close()
+
+
+def test_asynchronous_rebuild_in_the_animation_loop():
+    """main.cu:534-541 with crt_bvh_build_async / crt_bvh_swap: the rebuild of every 20th frame runs under the frames that
+    follow; every frame equals the loop that stops for a synchronous device rebuild (the image does not depend on the tree)."""
+    prims = np.concatenate([crt.scene_spheres(3000, seed=11), crt.scene_soup(20000, seed=12)])
+    cam, tgt = crt.default_camera()
+    W, H, N = 400, 225, 50
+    p = crt.default_params(width=W, height=H, bounces=2)
+    ref = crt.Context(0); ref.set_scene(prims); ref.set_lights(crt.default_lights()); ref.build(0)
+    want = []
+    for f in range(1, N + 1):
+        ref.animate_device()
+        if f % 20 == 0:
+            ref.build(2)
+        else:
+            ref.refit(False)
+        want.append(ref.render(cam, tgt, p).copy())
+    ref.close()
+    ctx = crt.Context(0); ctx.set_scene(prims); ctx.set_lights(crt.default_lights()); ctx.build(0)
+    try:
+        with pytest.raises(crt.CrtError):
+            ctx.swap()                                   # nothing under way
+        building, swaps, nodes0 = False, [], ctx.stats()["nodes"]
+        for f in range(1, N + 1):
+            ctx.animate_device()
+            if f % 20 == 0:
+                ctx.build_async(); building = True
+                with pytest.raises(crt.CrtError):
+                    ctx.build_async()                    # one at a time
+            if building and ctx.swap(wait=(f % 20 == 7)):      # by the 7th frame after the snapshot at the latest
+                building = False; swaps.append(f)
+            else:
+                ctx.refit(False)
+            got = ctx.render(cam, tgt, p)
+            assert np.array_equal(got, want[f - 1]), f"frame {f}"
+        assert len(swaps) == 2 and all(20 <= s_ <= 27 or 40 <= s_ <= 47 for s_ in swaps), swaps
+        assert ctx.stats()["nodes"] != nodes0            # the device-built tree is the current one
+        ids = ctx.reference_order()                      # ranks of the snapshot, served from the device
+        assert sorted(ids.tolist()) == list(range(len(prims)))
+        ctx.build_async()
+        ctx.set_scene(prims)                             # abandons the build under way
+        ctx.build(0)
+        assert np.array_equal(ctx.render(cam, tgt, p).shape, (H, W, 3))
+    finally:
+        ctx.close()

@@ -63,10 +63,18 @@ def spheres(n=4096, frames=60, width=1920, height=1080, bounces=2, rebuild_mode=
     p = crt.default_params(width=width, height=height, bounces=bounces)
     ctx.render_device(cam, tgt, p)
     upd, ren, kinds, rays = [], [], [], 0
+    building = False
     for f in range(1, frames + 1):
         t0 = time.perf_counter()
         ctx.animate_device()
-        if f % 20 == 0:
+        if rebuild_mode == 3:                   # device rebuild under the following frames (crt_bvh_build_async / crt_bvh_swap)
+            if f % 20 == 0:
+                ctx.build_async(); building = True
+            if building and ctx.swap(False):
+                building = False; kinds.append("swap")
+            else:
+                ctx.refit(False); kinds.append("rebuild" if f % 20 == 0 else "refit")
+        elif f % 20 == 0:
             ctx.build(rebuild_mode); kinds.append("rebuild")   # 0: host SAH build + upload, 2: LBVH on the device
         else:
             ctx.refit(False); kinds.append("refit")
@@ -74,9 +82,13 @@ def spheres(n=4096, frames=60, width=1920, height=1080, bounces=2, rebuild_mode=
         upd.append((time.perf_counter() - t0) * 1e3)
         ctx.render_device(cam, tgt, p)
         st = ctx.stats(); ren.append(st["ms_total"]); rays = rays_of(st)
+    if building:
+        ctx.swap(True)
     upd = np.array(upd); ren = np.array(ren); is_rb = np.array([k == "rebuild" for k in kinds])
+    swaps = [i + 1 for i, k in enumerate(kinds) if k == "swap"]
     print(json.dumps({"config": (label or f"configs[2]: {n} animated spheres") + f", {width}x{height}, bounces={bounces}, {frames} frames, "
-                                "device animation + refit every frame, " + ("host SAH" if rebuild_mode == 0 else "device LBVH") + " rebuild every 20th",
+                                "device animation + refit every frame, " + {0: "host SAH", 2: "device LBVH", 3: "asynchronous device LBVH"}[rebuild_mode] + " rebuild every 20th",
+                      "swap_frames": swaps, "frame_ms_worst_over_mean": round(float((upd + ren).max() / (upd + ren).mean()), 3),
                       "render_ms_mean": round(float(ren.mean()), 4), "render_ms_worst": round(float(ren.max()), 4),
                       "update_ms_refit_mean": round(float(upd[~is_rb].mean()), 4), "update_ms_refit_worst": round(float(upd[~is_rb].max()), 4),
                       "update_ms_rebuild_mean": round(float(upd[is_rb].mean()), 4),
@@ -132,9 +144,11 @@ if __name__ == "__main__":
     if "2" in which:
         spheres()
         spheres(rebuild_mode=2)
+        spheres(rebuild_mode=3)
     if "2big" in which:       # the animation loop on the 1M-triangle soup: only feasible with the device rebuild
         soup = crt.scene_soup(1000000, seed=1)
         spheres(frames=40, width=3840, height=2160, bounces=3, rebuild_mode=2, prims=soup, label="animation loop on the 1M-triangle soup")
+        spheres(frames=60, width=3840, height=2160, bounces=3, rebuild_mode=3, prims=soup, label="animation loop on the 1M-triangle soup")
         spheres(frames=21, width=3840, height=2160, bounces=3, rebuild_mode=0, prims=soup, label="animation loop on the 1M-triangle soup")
     if "4" in which:
         soup_8k_one_rank()
