@@ -1100,10 +1100,6 @@ int crt_render_submit(crt_ctx* c, int slot, const crt_camera* cam, const crt_par
     if (gb < 1) gb = 1;
     uint32_t* const ovf = c->d_ovf + (size_t)slot * c->ovf_slot_words;
     if (p->use_graph) { int e = 0; (void)frexpf(sabs > 0.f ? sabs : 1.f, &e); sabs = ldexpf(1.0f, e); }
-    /* per-ray shadow directions are stored only where they differ from ray to ray (point lights, area samples) or where the
-     * traversal kernel has no light table (the reference topology's k_trace) */
-    bool need_shD = c->hdr.mode != CRT_BVH_WIDE;
-    for (int j = 0; j < lights.n; j++) need_shD = need_shD || lights.l[j].area || lights.l[j].point;
     auto enqueue = [&]() {
     for (int s = 0; s < spp; s++) {
         uint32_t* ctr = f.d_ctr + (size_t)s * kCtrStride;
@@ -1111,7 +1107,7 @@ int crt_render_submit(crt_ctx* c, int slot, const crt_camera* cam, const crt_par
         int cur = 0;
         FrameBuffers fb{};
         fb.hitSlot = f.hitSlot; fb.hitT = f.hitT; fb.contrib = f.contrib; fb.shflag = f.shflag;
-        fb.shO = f.shO; fb.shD = need_shD ? f.shD : nullptr; fb.area_table = c->d_area_table; fb.accum = f.accum; fb.cap_ids = f.cap_ids; fb.cap_ts = f.cap_ts;
+        fb.shO = f.shO; fb.shD = f.shD; fb.area_table = c->d_area_table; fb.accum = f.accum; fb.cap_ids = f.cap_ids; fb.cap_ts = f.cap_ts;
         fb.cap = (uint32_t)f.cap; fb.cap_stride = (uint32_t)npix; fb.tile_ids = f.d_tiles;
         auto bind = [&](int k) {
             fb.rayO = f.rayO[k]; fb.rayD = f.rayD[k]; fb.coef = f.coef[k]; fb.pix = f.pix[k];
@@ -1148,11 +1144,7 @@ int crt_render_submit(crt_ctx* c, int slot, const crt_camera* cam, const crt_par
                 common(tm, 2 * b + 1);
                 const bool has_sh = c->lights.n > 0, has_nx = b + 1 < p->bounces;
                 if (has_sh) {
-                    tm.shO = f.shO; tm.shD = fb.shD; tm.shcount = ctr + 16 + b;
-                    if (!fb.shD) {          /* directions by light slot: every light is directional */
-                        tm.sh_cap = (uint32_t)f.cap; tm.sh_nslots = (uint32_t)lights.nslots;
-                        for (int j = 0; j < lights.n; j++) { memcpy(tm.sh_dir[j], lights.l[j].direction, 12); tm.sh_dir[j][3] = 0.f; }      /* normalised on the device, as k_shade does */
-                    }
+                    tm.shO = f.shO; tm.shD = f.shD; tm.shcount = ctr + 16 + b;
                     if (p->sort_rays) {
                         launch_sort_rays(f.shO, ctr + 16 + b, (uint32_t)(f.cap * (size_t)lights.nslots), d_root_box, f.d_sortkeys, f.d_sorthist,
                                          f.d_sortperm, f.stream);

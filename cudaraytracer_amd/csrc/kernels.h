@@ -117,7 +117,7 @@ struct FrameBuffers {
     int32_t* hitSlot; float* hitT;
     float4* contrib; uint8_t* shflag;
     const float4* area_table;                                          /* kAreaTable entries (u, cos, sin, 0) */
-    float4* shO; float4* shD;                                          /* shadow-ray queue: .w = target / light; shD null when every light is directional (k_trace8 takes the direction from the slot) */
+    float4* shO; float4* shD;                                          /* shadow-ray queue: .w = target / light */
     float4* accum;                                                     /* per pixel float colour (isect.color) */
     int32_t* cap_ids; float* cap_ts;                                   /* capture planes [bounce][pixel] or null */
     uint32_t cap;                                                      /* queue capacity: stride of the per-light planes */
@@ -135,10 +135,6 @@ struct TraceArgs {
     const float4* shO; const float4* shD;    /* k_trace8 only: the shadow queue served by the same launch, */
     const uint32_t* shcount;                 /* null = none (k_trace takes its one queue in rayO/rayD/count) */
     const uint32_t* shperm;
-    /* shD null: the queue carries no directions.  Light slot of a ray = plane number of its target = target / sh_cap;
-     * sh_dir[slot] = crt_light.direction of that (directional) light, sh_nslots of them */
-    uint32_t sh_cap, sh_nslots;
-    float sh_dir[CRT_MAX_LIGHTS][4];
     uint32_t* next;              /* 8 fetch counters, kFetchStride words apart (device, zeroed) */
     int32_t* hitSlot; float* hitT;           /* NEAREST outputs */
     uint8_t* shflag;                         /* SHADOW output, indexed by the target in rayO.w */

@@ -460,8 +460,6 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
     __shared__ uint32_t s_cnt[BLOCK];                /* lanes still working on the ray */
     __shared__ uint32_t s_best[BLOCK];               /* slot that holds the minimum */
     __shared__ uint8_t s_pair[BLOCK];                /* steal step: the wave's offering lanes, compacted */
-    /* shadow queue without per-ray directions (A.shD null: every light is directional): unit vector towards light slot k */
-    __shared__ float4 s_ldir[CRT_MAX_LIGHTS];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wbase = tid & ~63;
@@ -470,10 +468,6 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
         int y = 0;
         for (int k = 0; k < 8; k++) if ((m >> k) & 1) y |= 1 << (k ^ R_);
         s_perm[R_][m] = (uint8_t)y;
-    }
-    if (tid < CRT_MAX_LIGHTS && !A.shD && tid < (int)A.sh_nslots) {          /* toLight of Ray.cu:634, evaluated as k_shade evaluates it */
-        const vec3 tl = -normalize(vec3(A.sh_dir[tid][0], A.sh_dir[tid][1], A.sh_dir[tid][2]));
-        s_ldir[tid] = make_float4(tl.x, tl.y, tl.z, 0.f);
     }
     __syncthreads();
     /* one launch serves TWO independent queues: the shadow rays of a bounce and the nearest-hit rays of the
@@ -629,7 +623,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                     if (mine) {          /* issue the loads only: they complete under the traversal step below */
                         if (sh) {
                             const uint32_t q = A.shperm ? A.shperm[idx] : idx;      /* sorted visiting order, if any */
-                            pro4 = A.shO[q]; if (A.shD) prd = A.shD[q]; ray = q | 0x80000000u;
+                            pro4 = A.shO[q]; prd = A.shD[q]; ray = q | 0x80000000u;
                         } else {
                             const uint32_t q = A.perm ? A.perm[idx - ns64] : idx - ns64;
                             pro4 = A.rayO[q]; prd = A.rayD[q]; ray = q;
@@ -870,18 +864,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
             } else {
                 ray = idx;
                 o = vec3(ro.x, ro.y, ro.z); d = vec3(rd.x, rd.y, rd.z);
-                if (shray) {
-                    const uint32_t plane = __float_as_uint(ro.w);
-                    ray = plane | 0x80000000u; lkind = __float_as_uint(rd.w);
-                    if (!A.shD) {
-                        /* the queue holds (origin, target) only: the target's plane number is the light slot, and with nothing
-                         * but directional lights a slot is a light (k_shade wrote no direction: 16 B per ray less each way) */
-                        uint32_t slot = 0;
-                        for (uint32_t k = 1; k < A.sh_nslots; k++) slot += plane >= k * A.sh_cap ? 1u : 0u;
-                        const float4 ld = s_ldir[slot];
-                        d = vec3(ld.x, ld.y, ld.z); lkind = kShadowDirectional;
-                    }
-                }
+                if (shray) { ray = __float_as_uint(ro.w) | 0x80000000u; lkind = __float_as_uint(rd.w); }
                 /* v_rcp_f32 (1 ulp) instead of an IEEE division: the box test only has to be
                  * conservative and the pad below is 1e4 times that error */
                 float rx = __builtin_amdgcn_rcpf(d.x), ry = __builtin_amdgcn_rcpf(d.y), rz = __builtin_amdgcn_rcpf(d.z);
@@ -1577,7 +1560,7 @@ __global__ CRT_SHADE_BOUNDS void k_shade(FrameParams P, FrameBuffers B, SceneVie
                 if (want) {
                     const uint32_t ks = sh_run + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull));
                     B.shO[ks] = make_float4(sorg.x, sorg.y, sorg.z, __uint_as_float((uint32_t)plane));
-                    if (B.shD) B.shD[ks] = make_float4(toLight.x, toLight.y, toLight.z, __uint_as_float(lbits));
+                    B.shD[ks] = make_float4(toLight.x, toLight.y, toLight.z, __uint_as_float(lbits));
                 }
                 sh_run += (uint32_t)__popcll(wm);
             }
@@ -1600,7 +1583,10 @@ void launch_shade(const FrameParams& fp, const FrameBuffers& fb, const SceneView
                   const uint32_t* count, uint32_t* next_count, uint32_t* shadow_count, hipStream_t s) {
     /* grid-stride over the queue; no more blocks than the queue can have entries */
     uint32_t blocks = (fb.cap + 255u) / 256u;
-    static const uint32_t maxb = [] { const char* v = getenv("CRT_SHADE_BLOCKS"); return v ? (uint32_t)atoi(v) : 4096u; }();
+    /* the kernel is bound by the latency of its dependent gathers (hit slot -> geometry + shading record -> material), not by
+     * bytes: more, shorter blocks keep more of them in flight (4096 blocks: 1.60 ms of k_shade + k_resolve per 4K frame,
+     * 16384: 1.52; tools/exp/shade_grid.sh) */
+    static const uint32_t maxb = [] { const char* v = getenv("CRT_SHADE_BLOCKS"); return v ? (uint32_t)atoi(v) : 16384u; }();
     blocks = blocks < 1u ? 1u : (blocks > maxb ? maxb : blocks);
     hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, s, fp, fb, sv, lights, count, next_count, shadow_count);
 }
