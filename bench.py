@@ -124,20 +124,32 @@ def cpu_baseline(prims, lights, cam, tgt, width, height, bounces, max_threads):
     dt = time.perf_counter() - t0
     st = sc.stats(reset=True)
     sc.close()
-    # the reference's own case beside it (configs[0]: teapot + sphere, 720x360, bounces = 1, the whole frame)
+    # the reference's own case beside it (configs[0]: teapot + sphere, 720x360, bounces = 1, the whole frame), best of 3
     import cudaraytracer_amd as crt
     tp = orc.Scene(crt.scene_teapot(with_sphere=True))
     tp.build()
-    tp.stats(reset=True)
-    t0 = time.perf_counter()
-    tp.render(lights, cam, tgt, 720, 360, 1, nthreads=cores)
-    dt0 = time.perf_counter() - t0
-    st0 = tp.stats(reset=True)
-    t1 = time.perf_counter()
-    tp.render(lights, cam, tgt, 720, 360, 1, nthreads=1)          # once single-threaded, once on all cores
-    dt1 = time.perf_counter() - t1
+    dt0 = dt1 = 1e30
+    for _ in range(3):
+        tp.stats(reset=True)
+        t0 = time.perf_counter()
+        tp.render(lights, cam, tgt, 720, 360, 1, nthreads=cores)
+        dt0 = min(dt0, time.perf_counter() - t0)
+        st0 = tp.stats(reset=True)
+    for _ in range(3):
+        t1 = time.perf_counter()
+        tp.render(lights, cam, tgt, 720, 360, 1, nthreads=1)          # once single-threaded, once on all cores
+        dt1 = min(dt1, time.perf_counter() - t1)
     tp.close()
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {
+        "cpu_model": model, "host_cpus_visible": os.cpu_count(), "timing": "best of 3 for reference_case; one pass for the bounded soup sample",
         "reference_case": {"workload": "configs[0]: teapot3.obj + sphere, 720x360, bounces=1, whole frame", "value": round(st0["traversals"] / dt0 / 1e6, 3),
                            "unit": "Mrays/s", "frame_ms": round(dt0 * 1e3, 2), "traversals": st0["traversals"], "cores": cores,
                            "single_thread": {"value": round(st0["traversals"] / dt1 / 1e6, 3), "frame_ms": round(dt1 * 1e3, 1)}},
@@ -329,19 +341,33 @@ def main():
                  survey_bytes(cst["rays_shadow"], cst["box_tests_shadow"], cst["tri_tests_shadow"], cst["sph_tests_shadow"])) / n_launch_c
         # HBM-side bytes and SQ_INSTS_VALU per launch of the same kernel from the committed PMC passes (rocprofv3 cannot be
         # nested inside this process): quoted, with their source, only for the default workload those passes measured
-        traffic = pmc_valu = None
+        traffic = pmc_valu = pmc_lane_util = None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
         default_workload = (a.tris, fw, fh, a.bounces, a.spp, a.bvh, world) == (1000000, 3840, 2160, 3, 1, 0, 1)
         tsrc = None
+        pmc_matches_build = None          # None: no committed PMC pass applies to this workload
+        build_hash = None
+        try:
+            build_hash = json.load(open(ISA_MIX)).get("kernel_hash")
+        except Exception:
+            pass
         if default_workload and os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                traffic = float(tj["hbm_bytes_per_launch"])
-                pmc_valu = tj.get("valu_wave_instructions_per_launch")
+                # the committed PMC pass counts for THIS binary only if it profiled the same k_trace8 instruction stream: the
+                # build writes a hash of it (tools/isa_mix.py), tools/profile.sh stores the hash with the pass
+                pmc_matches_build = bool(build_hash) and tj.get("kernel_hash") == build_hash
                 tsrc = "profiles/latest_traffic.json <- " + str(tj.get("source", ""))
+                if pmc_matches_build:
+                    traffic = float(tj["hbm_bytes_per_launch"])
+                    pmc_valu = tj.get("valu_wave_instructions_per_launch")
+                    pmc_lane_util = tj.get("valu_lane_utilisation")
+                else:
+                    tsrc += " -- NOT USED: that pass profiled k_trace8 %s, this build is %s (re-run tools/profile.sh)" % (tj.get("kernel_hash"), build_hash)
             except Exception:
                 traffic = None
-        roof = {"kernel": "k_trace8" if wide else "k_trace<NEAREST>", "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches}
+        roof = {"kernel": "k_trace8" if wide else "k_trace<NEAREST>", "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches,
+                "pmc_matches_build": pmc_matches_build, "k_trace8_kernel_hash": build_hash}
         if wide and os.path.exists(ISA_MIX) and os.path.exists(UBENCH_VALU) and cst["sched_iterations"] > 0 and avg_s > 0:
             n_instr, n_cycles_meas, n_cycles, mix = valu_issue_model(cst)
             n_instr /= n_launch_c
@@ -408,6 +434,11 @@ def main():
                                "bytes_per_launch_survey_8d_formula": int(sur_b)}
         roof["traffic"] = traffic
         roof["traffic_source"] = tsrc
+        # SURVEY 8(d) / north_star: the fraction of the HBM-bandwidth roofline, from the counters (not from requested bytes)
+        roof["hbm_counter_frac"] = round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_s > 0 else None
+        # of the issue cycles in `frac`, the share that did work on a lane holding a ray (VALU lane utilisation of the same PMC pass)
+        roof["useful_lane_frac"] = round(roof["frac"] * pmc_lane_util, 4) if pmc_lane_util and roof.get("bound") == "valu_issue" else None
+        roof["valu_lane_utilisation_pmc"] = round(pmc_lane_util, 4) if pmc_lane_util else None
         if l1 and avg_s > 0 and lane_req > 0:
             roof["vector_l1"] = {"lane_requests_per_launch": int(lane_req), "achieved_g_lane_requests_per_s": round(lane_req / avg_s / 1e9, 1),
                                  "ceiling_all_l1_hits": l1["g_lane_requests_per_s"],

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 lib_path = os.environ.get("CRT_LIB") or os.path.join(_HERE, "libcrt_amd.so")   # CRT_LIB: A/B builds in experiments
 # the mesh BASELINE's configs name; kept once in the tree, beside the other golden data (CRT_TEAPOT_OBJ points elsewhere)
-TEAPOT_OBJ = os.environ.get("CRT_TEAPOT_OBJ") or os.path.join(_ROOT, "tests", "golden", "teapot3.obj")
+TEAPOT_OBJ = os.environ.get("CRT_TEAPOT_OBJ") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "teapot3.obj")
 
 if not os.path.exists(lib_path):
     raise ImportError(

@@ -6,11 +6,16 @@
  * explicit fmaf() of the box test, which only has to be conservative.
  *
  * Design (wave64, no MFMA -- nothing here is a dense contraction):
- *   k_trace      persistent waves pull rays from a queue in HBM; each lane walks the packed 4-wide
- *                BVH with its own stack in LDS (stack[depth][lane]: conflict-free per wave), idle
- *                lanes are refilled from the queue.  NEAREST = bvhTraverse (Ray.cu:184-236) with
- *                the reference's strict-'<' tie-break made tree-shape independent via reference
- *                ranks; SHADOW = the predicates of Ray.cu:621-629 / 650-656.
+ *   k_trace8     THE traversal kernel (CRT_BVH_WIDE, ~90 % of a frame): persistent waves pull rays from two queues in HBM
+ *                (the shadow rays of a bounce and the nearest-hit rays of the next share a launch); each lane walks the
+ *                compressed 8-wide tree (QNode8: 80-byte nodes, 8-bit plane codes decoded by v_perm_b32 + v_fma_mix_f32,
+ *                an inline-asm slab test yielding a hit MASK, no distance sort) with one 64-bit stack entry per level in
+ *                LDS (stack[depth][lane]); the wave votes between a node step and a primitive step each iteration; rays are
+ *                fetched in XCD-affine chunks; a second instantiation of the loop shares the work of a wave's last rays
+ *                among its idle lanes.  bvhTraverse (Ray.cu:184-236) with the reference's strict-'<' tie-break made
+ *                tree-shape independent via reference ranks; shadow predicates of Ray.cu:621-629 / 650-656.
+ *   k_trace      the same contract on the reference's own topology (CRT_BVH_REFERENCE: exact boxes, two children per
+ *                node, up to 64 primitives per leaf), 4-wide node format with a distance sort; one queue per launch.
  *   k_shade      RayIntersection's bookkeeping (Ray.cu:479-525), wallIntersection (Ray.cu:238-457)
  *                and Shade's light loop (Ray.cu:560-659), emitting compacted shadow / reflection
  *                queues with wave-aggregated atomics.

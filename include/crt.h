@@ -156,7 +156,9 @@ int crt_scene_get(crt_ctx*, crt_prim* prims_out, int n);        /* current scene
 #define CRT_BVH_WIDE_DEVICE 2 /* the same 8-wide format built on the device (Morton-order linear BVH, one primitive per leaf):
                               * milliseconds instead of a second for 1M primitives, for "rebuild every N frames" on large
                               * animated scenes.  Builds from the device copy of the scene (after crt_animate_device no
-                              * copy back); no reference-order pass: exact-t ties resolve by scene index */
+                              * copy back).  Exact-t ties resolve by the reference's leaf order here too: refrank.hip replays
+                              * newBuild + constructTree's partition on the device (scene index only where that recursion
+                              * does not terminate, as for CRT_BVH_WIDE) */
 int crt_bvh_build(crt_ctx*, int mode);
 /* "Rebuild every N frames" (main.cu:534-541) without the stall of a synchronous rebuild; no counterpart in the reference,
  * whose loop stops for its host build.  crt_bvh_build_async starts a CRT_BVH_WIDE_DEVICE build on a stream and a host

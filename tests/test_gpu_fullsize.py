@@ -67,3 +67,53 @@ def test_full_frame_accounting(soup):
     assert img.reshape(-1, 3).max(axis=1).min() > 0        # every pixel has ambient + something
     # rendering the same frame twice is bit-identical (queue order differs run to run, results must not)
     assert np.array_equal(img, ctx.render(cam, tgt, p))
+
+
+def test_config2_full_size_animation_loop():
+    """BASELINE configs[2] at its full size: 4096 spheres (seed 1), 1920x1080, bounces = 2, 60 frames, refit every frame and a
+    rebuild at frames 20 and 40 (main.cu:534-541).  Three contexts run the loop -- animation on the device + synchronous device
+    rebuild, animation on the device + ASYNCHRONOUS device rebuild (crt_bvh_build_async / crt_bvh_swap), animation on the host
+    (crt_animate_host + crt_scene_update) + host rebuild -- and must produce byte-equal frames, every frame; frames 0, 19, 20
+    and 59 are held against the oracle on three 160x90 windows each (bit-exact), and the final scene states are equal."""
+    import cudaraytracer_amd as crt
+    W, H, B, N = 1920, 1080, 2, 60
+    prims = crt.scene_spheres(4096, seed=1)
+    lights = crt.default_lights()
+    cam, tgt = crt.default_camera()
+    p = crt.default_params(width=W, height=H, bounces=B)
+    dev = crt.Context(0); asy = crt.Context(0); hst = crt.Context(0)
+    sc = orc.Scene(prims); sc.build()
+    host = prims.copy()
+    windows = [(200, 300, 360, 390), (880, 495, 1040, 585), (1500, 700, 1660, 790)]
+    try:
+        for c in (dev, asy, hst):
+            c.set_scene(prims); c.set_lights(lights); c.build(0)
+        building = False
+        for f in range(0, N):
+            if f > 0:
+                dev.animate_device(); asy.animate_device(); crt.animate_host(host); sc.animate()
+                if f % 20 == 0:
+                    dev.build(2)
+                    asy.build_async(); building = True
+                    hst.set_scene(host); hst.build(0)
+                    sc.build()
+                else:
+                    dev.refit(False); hst.update_scene(host); hst.refit(False); sc.refit()
+                if building and asy.swap(wait=(f % 20 == 5)):
+                    building = False
+                elif f % 20 != 0 or building:
+                    asy.refit(False)
+            g = dev.render(cam, tgt, p)
+            assert np.array_equal(g, asy.render(cam, tgt, p)), f"frame {f}: asynchronous rebuild differs"
+            assert np.array_equal(g, hst.render(cam, tgt, p)), f"frame {f}: host animation / host rebuild differs"
+            if f in (0, 19, 20, 59):
+                for (x0, y0, x1, y1) in windows:
+                    o = sc.render(lights, cam, tgt, W, H, B, rect=[x0, y0, x1, y1], nthreads=16)["bgr"]
+                    assert np.array_equal(g[y0:y1, x0:x1], o[y0:y1, x0:x1]), f"frame {f}: window {(x0, y0)} differs from the oracle"
+                assert g[windows[1][1]:windows[1][3], windows[1][0]:windows[1][2]].std() > 1        # the windows hold spheres, not an empty wall
+        assert not building
+        assert dev.get_scene().tobytes() == host.tobytes() == sc.prims().tobytes()
+        st = dev.stats()
+        assert st["rays_primary"] == W * H and st["rays_reflect"] > 0
+    finally:
+        dev.close(); asy.close(); hst.close(); sc.close()

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import orc
+from parity_classes import classify
 
 pytestmark = pytest.mark.gpu
 
@@ -16,7 +17,7 @@ T_RTOL = 1e-4          # north_star: hit t within 1e-4 relative
 LSB = 1                # north_star: 8-bit colour within 1 LSB
 # Both sides evaluate the reference's float expressions in the same order without contraction, and every run so far has
 # been exact, so the allowances are zero: an id flip, a t outside tolerance or a pixel beyond 1 LSB is a regression until
-# it has been assigned to one of SURVEY.md 9.1's classes (classify() below says which one a mismatch looks like).
+# it has been assigned to one of SURVEY.md 9.1's classes (parity_classes.classify says which one a mismatch is: it re-runs the box-free search on the ray to tell G3 from G1 and recomputes the predicate margins).
 MAX_ID_MISMATCH = 0
 
 
@@ -40,22 +41,7 @@ def teapot(crt):
     sc.close()
 
 
-def classify(ids_g, ts_g, ids_o, ts_o, bad):
-    """What the first mismatches look like, in the vocabulary of SURVEY.md 9.1: G2 (both sides report a hit at the
-    bit-identical t: a tie resolved differently), G1/G3 (one side misses, or the t differ: a threshold or box-face case)."""
-    out = []
-    for i in np.flatnonzero(bad)[:8]:
-        if ids_g[i] >= 0 and ids_o[i] >= 0 and ts_g[i] == ts_o[i]:
-            cls = "G2 equal-t tie"
-        elif (ids_g[i] < 0) != (ids_o[i] < 0):
-            cls = "G1/G3 hit on one side only"
-        else:
-            cls = "G1 different t"
-        out.append(f"ray {i}: gpu ({ids_g[i]}, {ts_g[i]!r}) oracle ({ids_o[i]}, {ts_o[i]!r}) -> {cls}")
-    return "; ".join(out)
-
-
-def compare_hits(ids_g, ts_g, ids_o, ts_o, what):
+def compare_hits(ids_g, ts_g, ids_o, ts_o, what, sc=None, rays=None, prims=None):
     n = len(ids_o)
     bad_id = ids_g != ids_o
     hit = (ids_o >= 0) & ~bad_id
@@ -63,7 +49,7 @@ def compare_hits(ids_g, ts_g, ids_o, ts_o, what):
     n_t = int((rel > T_RTOL).sum())
     print(f"{what}: rays={n} hits={int((ids_o >= 0).sum())} id_mismatch={int(bad_id.sum())} "
           f"t_exact={int((ts_g[hit] == ts_o[hit]).sum())}/{int(hit.sum())} t_out_of_tol={n_t}")
-    assert bad_id.sum() <= MAX_ID_MISMATCH, f"{what}: {bad_id.sum()} nearest-hit id mismatches: {classify(ids_g, ts_g, ids_o, ts_o, bad_id)}"
+    assert bad_id.sum() <= MAX_ID_MISMATCH, f"{what}: {bad_id.sum()} nearest-hit id mismatches: {classify(ids_g, ts_g, ids_o, ts_o, bad_id, sc, rays, prims)}"
     assert n_t == 0, f"{what}: {n_t} hit distances beyond {T_RTOL} relative"
     return int(bad_id.sum())
 
@@ -75,7 +61,7 @@ def test_trace_teapot_primary(crt, teapot):
     ids_g, ts_g = ctx.trace(rays)
     ids_o, ts_o = sc.trace(rays)
     assert (ids_o >= 0).sum() > 25000
-    compare_hits(ids_g, ts_g, ids_o, ts_o, "teapot primary 720x360")
+    compare_hits(ids_g, ts_g, ids_o, ts_o, "teapot primary 720x360", sc, rays, prims)
 
 
 def test_trace_random_rays_both_topologies(crt, teapot):
@@ -96,7 +82,7 @@ def test_trace_random_rays_both_topologies(crt, teapot):
     rays = np.concatenate([o, d.astype(np.float32)], axis=1)
     ids_o, ts_o = sc.trace(rays)
     ids_g, ts_g = ctx.trace(rays)
-    compare_hits(ids_g, ts_g, ids_o, ts_o, "random rays, wide BVH")
+    compare_hits(ids_g, ts_g, ids_o, ts_o, "random rays, wide BVH", sc, rays, prims)
     # the same kernel on the reference's own topology (mean-centroid split, 64-primitive leaves)
     ctx2 = crt.Context(0)
     ctx2.set_scene(prims)
@@ -361,7 +347,8 @@ def test_equal_t_ties_resolve_to_the_reference_order(crt):
     split still terminates.  Coincident copies always share a reference leaf, whose order is the scene order (stable
     partition, bvh.cu:58-68), so the reference's winner is the copy with the lowest scene index -- which is also what
     a brute-force loop in scene order keeps.  Ids, t and the image must equal the oracle's on every tree the library
-    builds: the wide tree breaks ties by reference rank, the device-built one by scene index."""
+    builds: all three break ties by the reference's leaf rank (the host builders take it from their restatement of
+    constructTree, the device build replays the partition on the device, refrank.hip)."""
     base = crt.scene_teapot(with_sphere=True)
     rng = np.random.default_rng(3)
     prims = np.concatenate([base, base, base[rng.permutation(len(base))]])
@@ -385,7 +372,7 @@ def test_equal_t_ties_resolve_to_the_reference_order(crt):
         try:
             ctx.set_scene(prims); ctx.set_lights(lights); ctx.build(mode)
             ids_g, ts_g = ctx.trace(rays)
-            assert np.array_equal(ids_g, ids_o), f"mode {mode}: {classify(ids_g, ts_g, ids_o, ts_o, ids_g != ids_o)}"
+            assert np.array_equal(ids_g, ids_o), f"mode {mode}: {classify(ids_g, ts_g, ids_o, ts_o, ids_g != ids_o, None, rays, prims)}"
             assert np.array_equal(ts_g.view(np.uint32)[hits], ts_o.view(np.uint32)[hits])
             got = ctx.render(cam, tgt, crt.default_params(width=360, height=180, bounces=3))
             assert np.array_equal(got, want), f"mode {mode}: image differs on the all-ties scene"

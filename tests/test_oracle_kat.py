@@ -120,3 +120,32 @@ def test_refit_grows_only_and_animation_runs():
     after = sc.dump()["boxes"]
     assert np.all(after[:, 0::2] <= before[:, 0::2]) and np.all(after[:, 1::2] >= before[:, 1::2])
     assert np.any(after != before)
+
+
+def test_mismatch_classifier_tells_the_classes_apart():
+    """tests/parity_classes.py words the failure of a parity test: fed fabricated mismatches it must name G2 for a tie,
+    G3 when the reference's own tree and its own brute-force loop disagree, and G1 with the grazing predicate otherwise."""
+    import cudaraytracer_amd as crt
+    from parity_classes import classify, margins
+    prims = crt.scene_teapot(with_sphere=True)
+    sc = orc.Scene(prims); sc.build()
+    cam, tgt = crt.default_camera()
+    rays = orc.primary_rays(cam, tgt, 120, 60)
+    ids_o, ts_o = sc.trace(rays)
+    hit = np.flatnonzero(ids_o >= 0)
+    assert len(hit) > 100
+    ids_g, ts_g = ids_o.copy(), ts_o.copy()
+    a, b, c = hit[0], hit[1], hit[2]
+    ids_g[a] = (ids_o[a] + 1) % len(prims)                      # same t, other primitive: a tie resolved differently
+    ids_g[b] = -1; ts_g[b] = 1e9                                # the "gpu" misses what the oracle hits
+    msg = classify(ids_g, ts_g, ids_o, ts_o, ids_g != ids_o, sc, rays, prims)
+    assert f"ray {a}:" in msg and "G2 equal-t tie" in msg.split(f"ray {b}:")[0]
+    assert "G1 threshold grazing" in msg.split(f"ray {b}:")[1] and "nearest predicate" in msg
+    # G3: pretend the reference's tree had lost hit c (what a box false-negative looks like from outside)
+    ids_f, ts_f = ids_o.copy(), ts_o.copy()
+    ids_f[c] = -1; ts_f[c] = 1e9
+    msg3 = classify(ids_o, ts_o, ids_f, ts_f, ids_o != ids_f, sc, rays, prims)
+    assert "G3 box false-negative" in msg3 and "agrees with the brute-force result" in msg3
+    m = margins(prims[ids_o[c]], rays[c])
+    assert all(v > 0 for v in m.values())                      # a solid hit passes every predicate with room
+    sc.close()

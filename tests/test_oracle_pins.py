@@ -45,7 +45,7 @@ def test_vec3_restatement_matches_vendored_glm_live(tmp_path):
 
 def test_obj_loader_matches_reference_golden():
     z = np.load(os.path.join(G, "teapot_obj.npz"))
-    v, n = orc.load_obj(os.path.join(G, "teapot3.obj"))
+    v, n = orc.load_obj(os.path.join(os.path.dirname(os.path.dirname(G)), "cudaraytracer_amd", "data", "teapot3.obj"))
     assert v.shape == (3072, 3)            # main.cu:236 hard-codes 3072 corners
     assert np.array_equal(bits(v), bits(z["verts"])) and np.array_equal(bits(n), bits(z["normals"]))
 

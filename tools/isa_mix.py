@@ -83,8 +83,12 @@ def main():
     region = "prologue"
     regions = {}
     unknown = {}
+    import hashlib
+    digest = hashlib.sha256()       # of the kernel's instruction stream: ties a PMC pass to the binary it profiled (bench.py pmc_matches_build)
     for line in lines[start + 1:]:
         t = line.strip()
+        if t and t[0] not in ";." and not t.endswith(":"):
+            digest.update((" ".join(t.split(";")[0].split()) + "\n").encode())
         if t.startswith("s_endpgm"):
             break
         m = re.match(r";\s*CRT_MARK\s+(\w+)", t)
@@ -116,7 +120,7 @@ def main():
             r["lds"] += 1
     for r in regions.values():
         r["valu_issue_cycles"] = round(r["valu_issue_cycles"], 2)
-    res = {"kernel": "k_trace8<false>", "waves_per_simd": k, "cost_source": ub,
+    res = {"kernel": "k_trace8<false, 256>", "kernel_hash": digest.hexdigest()[:16], "waves_per_simd": k, "cost_source": ub,
            "cycles_full_rate": cost["v_mov_b32"], "cycles_half_rate": half_default, "cycles_quarter_rate": cost["v_rcp_f32"],
            "regions": regions, "opcodes_priced_as_half_rate_by_default": unknown}
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)

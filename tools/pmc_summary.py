@@ -97,6 +97,14 @@ def main():
                 e["wait_any_frac_of_wave_cycles"] = pm["SQ_WAIT_ANY"] * 4 / pm["SQ_WAVE_CYCLES"] if False else pm["SQ_WAIT_ANY"] / pm["SQ_WAVE_CYCLES"]
         if "SQ_THREAD_CYCLES_VALU" in pm and pm.get("SQ_ACTIVE_INST_VALU", 0) > 0:
             e["valu_lane_utilisation"] = pm["SQ_THREAD_CYCLES_VALU"] / (pm["SQ_ACTIVE_INST_VALU"] * 64)
+        if pm.get("SQ_BUSY_CYCLES", 0) > 0 and "SQ_ACTIVE_INST_VALU" in pm:
+            e["active_inst_valu_over_busy_cycles"] = pm["SQ_ACTIVE_INST_VALU"] / pm["SQ_BUSY_CYCLES"]
+        if pm.get("GRBM_GUI_ACTIVE", 0) > 0 and "SQ_ACTIVE_INST_VALU" in pm:
+            # rocprof's derived VALUBusy: 4 x SQ_ACTIVE_INST_VALU / SIMDs / clocks.  On gfx950 SQ_ACTIVE_INST_VALU advances once per
+            # VALU wave-instruction (it equals SQ_INSTS_VALU within 1 %), so the formula prices every instruction at 4 cycles: a mix
+            # of 2-cycle and 4-cycle opcodes that saturates the SIMDs reads above 1 here and as its true cycles/instruction x count
+            # in bench.py's roofline.frac
+            e["valu_busy_rocprof_formula"] = 4 * pm["SQ_ACTIVE_INST_VALU"] / 1024 / (pm["GRBM_GUI_ACTIVE"] / 8)
         if pm.get("GRBM_GUI_ACTIVE", 0) > 0 and e.get("avg_ms", 0) > 0:
             e["clock_ghz"] = pm["GRBM_GUI_ACTIVE"] / 8 / (e["avg_ms"] * 1e6)          # the counter sums the 8 XCDs
             if "SQ_WAVE_CYCLES" in pm:
@@ -112,6 +120,12 @@ def main():
                 out["bench_line_under_kernel_trace"] = json.loads(open(p).read().strip().splitlines()[-1])
             except Exception:
                 pass
+    khash = None
+    try:
+        khash = json.load(open(os.path.join(src, "isa_mix.json"))).get("kernel_hash")
+    except Exception:
+        pass
+    out["k_trace8_kernel_hash"] = khash
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     json.dump(out, open(dst + ".json", "w"), indent=1, sort_keys=True)
     # HBM-side traffic of the dominant kernel for bench.py's roofline.traffic (it cannot collect PMC itself)
@@ -121,6 +135,9 @@ def main():
                        "write_size_kib_per_launch": e["pmc_per_launch_avg"]["WRITE_SIZE"],
                        "hbm_bytes_per_launch": e["hbm_read_bytes_per_launch_x2_gfx950"] + e["hbm_write_bytes_per_launch"],
                        "valu_wave_instructions_per_launch": e["pmc_per_launch_avg"].get("SQ_INSTS_VALU"),
+                       "valu_lane_utilisation": e.get("valu_lane_utilisation"),
+                       "valu_busy_rocprof_formula": e.get("valu_busy_rocprof_formula"),
+                       "kernel_hash": khash, "avg_launch_ms_under_kernel_trace": e.get("avg_ms"),
                        "rule": "FETCH_SIZE KiB x 1024 x 2 (gfx950 counts a 128-byte read request as 64 bytes) + WRITE_SIZE KiB x 1024, "
                                "MI355X_MICROARCH.md 'HBM'; the x2 is calibrated for 16-byte-per-lane reads, which these are",
                        "source": dst + ".json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, "
@@ -132,9 +149,9 @@ def main():
                 "profiler's figure / the code object's `.vgpr_count` (+ bytes of scratch) from the compiler's assembly, which is what "
                 "DESIGN.md quotes and what sets the occupancy.  Waves/SIMD = 4 x SQ_WAVE_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024): "
                 "resident waves per SIMD averaged over the launch (separate PMC passes of the same command).\n\n"
-                "| kernel | calls | avg ms | % | VGPR prof / ISA (+scratch B) | LDS | waves/SIMD | clock GHz | L2 hit | HBM read/launch (raw, x2) | HBM write/launch | VALU lane util |\n|---|---|---|---|---|---|---|---|---|---|---|---|\n")
+                "| kernel | calls | avg ms | % | VGPR prof / ISA (+scratch B) | LDS | waves/SIMD | clock GHz | L2 hit | HBM read/launch (raw, x2) | HBM write/launch | VALU lane util | VALUBusy = 4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs / clocks | SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES |\n|---|---|---|---|---|---|---|---|---|---|---|---|---|---|\n")
         for k, e in sorted(out["kernels"].items(), key=lambda kv: -kv[1].get("total_ms", 0)):
-            f.write("| {} | {} | {:.4f} | {:.2f} | {} | {} | {} | {} | {} | {} | {} | {} |\n".format(
+            f.write("| {} | {} | {:.4f} | {:.2f} | {} | {} | {} | {} | {} | {} | {} | {} | {} | {} |\n".format(
                 k, e.get("calls", ""), e.get("avg_ms", 0), e.get("pct", 0),
                 "{} / {}".format(e.get("vgpr", ""), "{} (+{})".format(e["isa"].get("vgpr"), e["isa"].get("scratch")) if "isa" in e else "?"),
                 e.get("lds", ""),
@@ -143,7 +160,14 @@ def main():
                 "{:.3f}".format(e["l2_hit_rate"]) if "l2_hit_rate" in e else "",
                 "{:.1f} MB, {:.1f} MB".format(e["hbm_read_bytes_per_launch_raw"] / 1e6, e["hbm_read_bytes_per_launch_x2_gfx950"] / 1e6) if "hbm_read_bytes_per_launch_raw" in e else "",
                 "{:.1f} MB".format(e["hbm_write_bytes_per_launch"] / 1e6) if "hbm_write_bytes_per_launch" in e else "",
-                "{:.3f}".format(e["valu_lane_utilisation"]) if "valu_lane_utilisation" in e else ""))
+                "{:.3f}".format(e["valu_lane_utilisation"]) if "valu_lane_utilisation" in e else "",
+                "{:.3f}".format(e["valu_busy_rocprof_formula"]) if "valu_busy_rocprof_formula" in e else "",
+                "{:.2f}".format(e["active_inst_valu_over_busy_cycles"]) if "active_inst_valu_over_busy_cycles" in e else ""))
+        f.write("\nVALUBusy: rocprof's derived formula prices every VALU wave-instruction at 4 cycles (on gfx950 SQ_ACTIVE_INST_VALU counts "
+                "instructions: it equals SQ_INSTS_VALU within 1 %), so a saturated mix of 2- and 4-cycle opcodes reads above 1; bench.py's "
+                "roofline.frac prices the same count with the kernel's own cycles per instruction.  SQ_BUSY_CYCLES sums 32 shader-engine "
+                "counters (8 XCDs x 4), hence ratios of ~8 for a kernel that issues on every SIMD.  k_trace8 kernel hash of these passes: "
+                + str(khash) + "\n")
     print("wrote", dst + ".json", dst + ".md")
 
 

@@ -7,6 +7,7 @@ TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
+cp cudaraytracer_amd/isa_mix_k_trace8.json $OUT/isa_mix.json     # which k_trace8 these passes profile (its kernel_hash)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench_kt.json 2> $OUT/kt.err || { echo "kernel trace failed"; tail -5 $OUT/kt.err; exit 1; }
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
