@@ -193,6 +193,21 @@ __device__ __forceinline__ float4 load_agent(const float4* p) {
     return make_float4(__uint_as_float((uint32_t)a), __uint_as_float((uint32_t)(a >> 32)), __uint_as_float((uint32_t)b), __uint_as_float((uint32_t)(b >> 32)));
 }
 
+/* Ordering of the bottom-up fit.  On gfx950 (as on gfx94x) an agent-scope relaxed atomic store is a write-through store (sc1)
+ * that is visible to every CU of the device once it is acknowledged, and s_waitcnt vmcnt(0) waits for that acknowledgement;
+ * an agent-scope relaxed atomic load (sc1) bypasses the non-coherent levels.  So "stores, s_waitcnt vmcnt(0), counter" on
+ * the writer and "counter, loads" on the reader order the boxes without the release / acquire fence pair, each of which is
+ * an L2 write-back on a chip with eight L2s (3.67 ms -> 0.17 ms for 1M primitives).  This is an ARCHITECTURE assumption, outside
+ * the HIP / C++ memory model (relaxed atomics give no happens-before): it is taken only when compiling for gfx950; any
+ * other target gets the fences. */
+#if defined(__gfx950__)
+#define CRT_FIT_PUBLISH() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define CRT_FIT_ACQUIRE() asm volatile("" ::: "memory")
+#else
+#define CRT_FIT_PUBLISH() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#define CRT_FIT_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#endif
+
 /* boxes bottom-up, one thread per leaf.  A thread carries the box of the subtree it has finished; at the parent the
  * first child to arrive (agent-scope counter) stops, the second reads its sibling's box, merges, stores the parent's
  * box and carries on.  Order at every node: box stores (agent scope), s_waitcnt vmcnt(0) = the stores are acknowledged,
@@ -205,10 +220,10 @@ __global__ __launch_bounds__(256) void k_lbvh_fit(const float4* plo, const float
     float4 mlo = plo[vals[j]], mhi = phi[vals[j]];
     uint32_t node = parent[n - 1 + j];
     for (int guard = 0; guard < 4096 && node != kNone; guard++) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CRT_FIT_PUBLISH();
         const uint32_t prev = __hip_atomic_fetch_add(&flags[node], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prev == 0u) return;
-        asm volatile("" ::: "memory");
+        CRT_FIT_ACQUIRE();
         const uint32_t cl = left[node], cr = right[node];
         const uint32_t sib = cl == me ? cr : cl;
         float4 slo, shi;

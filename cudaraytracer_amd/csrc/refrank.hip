@@ -338,6 +338,14 @@ int refrank_build(void* scratch, const crt_prim* d_prims, uint32_t n, const floa
     uint32_t level = 0, bound = nseg;                  /* bound >= the true count */
     int cbuf = 0, since = 0;
     while (bound > 0) {
+        if (level + 1 > 257 && since > 0) {
+            /* `bound` is only an upper estimate between read-backs: a tree whose last split is at depth 256 -- which the host
+             * builder accepts -- must not fail here because of launches that would have found nothing to do */
+            RR(hipMemcpyAsync(&nseg, S.ctr + cbuf, 4, hipMemcpyDeviceToHost, s));
+            RR(hipStreamSynchronize(s));
+            bound = nseg; since = 0;
+            if (bound == 0) break;
+        }
         if (++level > 257) {       /* level L splits the nodes of depth L-1; bvh_build.cpp gives up beyond depth 256 */
             RR(hipStreamSynchronize(s));
             if (err) *err = "refrank_build: the reference's split does not terminate on this scene";

@@ -222,9 +222,10 @@ int crt_trace_shadow(crt_ctx*, const float* org_dir, int n, uint8_t* shadowed_ou
  * tests hold it against the oracle's, value by value. */
 int crt_powf_probe(crt_ctx*, const float* x, const float* y, int n, float* out);
 /* crt_trace for callers that cannot allocate.  No counterpart in the reference (like crt_trace itself); it exists for
- * code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc: crt_trace allocates and frees
- * its working buffers on every call, this entry point calls no hipMalloc / hipFree / event or other allocating
- * routine.  Same kernels, same results; rays and results are DEVICE pointers (6n floats in, n ids and n t out).  The
+ * tight serving loops, harnesses that forbid hipMalloc and code that must not disturb an allocator (e.g. one preparing a
+ * graph capture elsewhere): crt_trace allocates and frees its working buffers on every call, this entry point calls no
+ * hipMalloc / hipFree / event or other allocating routine.  It does copy the status word to the host and synchronise the
+ * context's stream, so it cannot itself run INSIDE a stream capture.  Same kernels, same results; rays and results are DEVICE pointers (6n floats in, n ids and n t out).  The
  * working buffers (packed ray queue, hit slots, fetch counters) live in one fixed device array per GPU of
  * 36 MiB + 4 KiB, held until the process ends, which bounds n: CRT_ERR_ARG beyond CRT_NOALLOC_MAX_RAYS.  All calls on
  * one GPU share that array: calls that overlap on one GPU (two contexts, two threads) race -- serialise them.

@@ -31,6 +31,14 @@ def main():
     for f in range(1, frames + 1):                       # replicated animation: refit, every 4th step a device rebuild
         sr.animate(rebuild=(f % 4 == 0))
         frame = sr.render(cam, tgt, p, pipelined=pipelined)
+    resize = os.environ.get("CRT_TEST_RESIZE")          # "WxH": change the resolution while pipelined frames are in flight
+    if resize:
+        w, h = (int(v) for v in resize.split("x"))
+        p = crt.default_params(width=w, height=h, bounces=bounces)
+        for _ in range(3):                               # the first call finds frames of the old size in flight: they are completed first
+            frame = sr.render(cam, tgt, p, pipelined=pipelined)
+        if not pipelined:
+            frame = sr.render(cam, tgt, p, pipelined=False)
     if pipelined:
         frame = sr.finish()                              # render() returned the frame before; this is the last one
     if rank == 0:

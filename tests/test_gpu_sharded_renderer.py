@@ -65,3 +65,30 @@ def test_sharded_renderer_animates_on_every_rank(tmp_path, pipelined):
     finally:
         ctx.close()
     assert np.array_equal(np.load(out), full)
+
+
+def test_resolution_change_between_pipelined_renders(tmp_path):
+    """frames of the old size are still in flight when the size changes: they are completed against their own buffers before
+    frames, packed tiles and gather buffers are replaced (a smaller frame would otherwise be unpacked out of bounds); then a
+    non-pipelined render after pipelined ones finishes what is pending first."""
+    import cudaraytracer_amd as crt
+    world, mode, w, h, bounces = 2, 0, 450, 270, 2
+    w2, h2 = 200, 110
+    for pipelined in (1, 0):
+        out = str(tmp_path / f"resize{pipelined}.npy")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29551 + pipelined), WORLD_SIZE=str(world),
+                   CRT_TEST_PIPELINED=str(pipelined), CRT_TEST_RESIZE=f"{w2}x{h2}")
+        procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), out, str(w), str(h), str(bounces), str(mode)],
+                                  env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+        logs = [p.communicate(timeout=600)[0] for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+        prims = np.concatenate([crt.scene_teapot(with_sphere=True), crt.scene_soup(5000, seed=6)])
+        ctx = crt.Context(0)
+        ctx.set_scene(prims); ctx.set_lights(crt.default_lights()); ctx.build(mode)
+        cam, tgt = crt.default_camera()
+        try:
+            full = ctx.render(cam, tgt, crt.default_params(width=w2, height=h2, bounces=bounces))
+        finally:
+            ctx.close()
+        got = np.load(out)
+        assert got.shape == (h2, w2, 3) and np.array_equal(got, full)
