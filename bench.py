@@ -500,6 +500,32 @@ def main():
             for _ in range(3):
                 ctx.render(cam, tgt, params)
             out["config"]["frame_ms_with_d2h_copy"] = round((time.perf_counter() - t1) / 3 * 1e3, 4)
+        if world == 1:
+            # throughput with several frames in flight on the context's frame slots (crt_render_submit / crt_render_wait): the
+            # launches of one frame run in the tails of the other frames' persistent launches.  Beside `value`, which keeps
+            # one frame complete before the next starts (its per-kernel times are what the roofline prices)
+            K = 3
+            q = crt.api.Params.from_buffer_copy(params)
+            q.timing = 1
+            busy = [False] * K
+
+            def run(n):
+                for i in range(n):
+                    k = 1 + i % K
+                    if busy[k - 1]:
+                        ctx.render_wait(k)
+                    ctx.render_submit(k, cam, tgt, q)
+                    busy[k - 1] = True
+                for k in range(1, K + 1):
+                    if busy[k - 1]:
+                        ctx.render_wait(k)
+                        busy[k - 1] = False
+            run(2 * K)
+            t1 = time.perf_counter()
+            run(4 * K)
+            ms_pipe = (time.perf_counter() - t1) / (4 * K) * 1e3
+            out["config"]["frames_in_flight"] = {"slots": K, "ms_per_frame": round(ms_pipe, 4), "mrays_per_s": round(total_rays / ms_pipe / 1e3, 1),
+                                                 "note": "same frames, same kernels, three frames in flight on frame slots 1..3; not `value`"}
         if a.out_bmp and world == 1:
             crt.write_bmp(a.out_bmp, ctx.render(cam, tgt, params), fw, fh)
         if world == 1 and a.bvh != 2:
