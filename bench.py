@@ -175,6 +175,9 @@ def main():
     ap.add_argument("--bounces", type=int, default=3)
     ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--no-pipeline", action="store_true", help="N>1: finish every frame's tile gather before the next frame starts")
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="N=1: after the timed region, also measure the throughput with this many (1..3) frames in "
+                    "flight on the context's frame slots (config.frames_in_flight; off by default so that a kernel trace of the default command holds "
+                    "only launches that ran alone)")
     ap.add_argument("--slots", type=int, default=3, help="N>1: frames in flight per rank (crt_render_submit on frame slots 1..slots)")
     ap.add_argument("--bvh", type=int, default=0, help="0 wide SAH built on the host (default), 1 reference topology, 2 wide LBVH built on the device")
     ap.add_argument("--sort-rays", type=int, default=0, help="1: visit secondary rays in Morton order of their origin cell")
@@ -500,11 +503,11 @@ def main():
             for _ in range(3):
                 ctx.render(cam, tgt, params)
             out["config"]["frame_ms_with_d2h_copy"] = round((time.perf_counter() - t1) / 3 * 1e3, 4)
-        if world == 1:
+        if world == 1 and a.frames_in_flight:
             # throughput with several frames in flight on the context's frame slots (crt_render_submit / crt_render_wait): the
             # launches of one frame run in the tails of the other frames' persistent launches.  Beside `value`, which keeps
             # one frame complete before the next starts (its per-kernel times are what the roofline prices)
-            K = 3
+            K = max(1, min(3, a.frames_in_flight))
             q = crt.api.Params.from_buffer_copy(params)
             q.timing = 1
             busy = [False] * K
@@ -525,7 +528,7 @@ def main():
             run(4 * K)
             ms_pipe = (time.perf_counter() - t1) / (4 * K) * 1e3
             out["config"]["frames_in_flight"] = {"slots": K, "ms_per_frame": round(ms_pipe, 4), "mrays_per_s": round(total_rays / ms_pipe / 1e3, 1),
-                                                 "note": "same frames, same kernels, three frames in flight on frame slots 1..3; not `value`"}
+                                                 "note": "same frames, same kernels, frames in flight on frame slots 1..K; not `value`"}
         if a.out_bmp and world == 1:
             crt.write_bmp(a.out_bmp, ctx.render(cam, tgt, params), fw, fh)
         if world == 1 and a.bvh != 2:
