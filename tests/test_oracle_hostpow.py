@@ -65,7 +65,7 @@ def test_float_and_double_pow_readings_differ_by_a_bounded_handful(tmp_path):
         # the classes are the same grazing classes as SURVEY 9.1 G1 (a predicate a few ulp from its threshold) and G5
         # (8-bit truncation): a handful of rays, never a visible difference
         assert r["ids_differ"] <= 2e-4 * r["rays"], (name, r)
-        assert r["t_max_rel"] <= 1e-4, (name, r)
+        assert r["t_max_rel"] <= 1e-3, (name, r)
         assert r["pixels_differ"] <= 2e-3 * r["pixels"], (name, r)
         assert r["pixels_beyond_1_lsb"] <= 1e-4 * r["pixels"], (name, r)
     # and the two readings are NOT identical on these scenes (for r = 20, the reference's own sphere, they are): the switch works
