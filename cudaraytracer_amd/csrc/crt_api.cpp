@@ -31,10 +31,13 @@ using namespace crt;
 
 namespace {
 constexpr int kMaxBounces = 16;
-/* per sample pass: [0..15] queue sizes per bounce, [16..31] shadow-queue sizes, then 32 launches x 8 region
- * fetch counters kFetchStride words apart */
+/* per sample pass: [0..15] queue sizes per bounce, then 32 launches x 8 region fetch counters kFetchStride words apart,
+ * then (kCtrShadow0) the shadow-queue sizes per bounce */
 constexpr int kCtrFetch0 = 64;
-constexpr int kCtrStride = kCtrFetch0 + 32 * 8 * kFetchStride;
+/* the shadow-queue sizes sit 4 KB and more from the queue sizes: k_shade adds to one of each per block iteration, and two hot
+ * words in one 128-byte line share an L2 channel's atomic unit */
+constexpr int kCtrShadow0 = kCtrFetch0 + 32 * 8 * kFetchStride + 1024;
+constexpr int kCtrStride = kCtrShadow0 + 1024;
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 }
 
@@ -1135,7 +1138,7 @@ int crt_render_submit(crt_ctx* c, int slot, const crt_camera* cam, const crt_par
                 launch_trace(ta, TRACE_NEAREST, c->counting, wide, gb, f.stream);
                 mark(f, EV_TRACE_N);
             }
-            launch_shade(fp, fb, sv, lights, ctr + b, ctr + b + 1, ctr + 16 + b, f.stream);
+            launch_shade(fp, fb, sv, lights, ctr + b, ctr + b + 1, ctr + kCtrShadow0 + b, f.stream);
             mark(f, EV_SHADE);
             if (wide) {
                 /* ONE launch for the shadow rays of this bounce and the nearest-hit rays of the next: they are
@@ -1144,9 +1147,9 @@ int crt_render_submit(crt_ctx* c, int slot, const crt_camera* cam, const crt_par
                 common(tm, 2 * b + 1);
                 const bool has_sh = c->lights.n > 0, has_nx = b + 1 < p->bounces;
                 if (has_sh) {
-                    tm.shO = f.shO; tm.shD = f.shD; tm.shcount = ctr + 16 + b;
+                    tm.shO = f.shO; tm.shD = f.shD; tm.shcount = ctr + kCtrShadow0 + b;
                     if (p->sort_rays) {
-                        launch_sort_rays(f.shO, ctr + 16 + b, (uint32_t)(f.cap * (size_t)lights.nslots), d_root_box, f.d_sortkeys, f.d_sorthist,
+                        launch_sort_rays(f.shO, ctr + kCtrShadow0 + b, (uint32_t)(f.cap * (size_t)lights.nslots), d_root_box, f.d_sortkeys, f.d_sorthist,
                                          f.d_sortperm, f.stream);
                         tm.shperm = f.d_sortperm;
                         mark(f, EV_SORT);
@@ -1167,7 +1170,7 @@ int crt_render_submit(crt_ctx* c, int slot, const crt_camera* cam, const crt_par
             } else if (c->lights.n > 0) {
                 TraceArgs ts{};
                 common(ts, 2 * b + 1);
-                ts.rayO = f.shO; ts.rayD = f.shD; ts.count = ctr + 16 + b;
+                ts.rayO = f.shO; ts.rayD = f.shD; ts.count = ctr + kCtrShadow0 + b;
                 ts.hitSlot = nullptr; ts.hitT = nullptr; ts.counters = c->d_testctr + 16;
                 launch_trace(ts, TRACE_SHADOW, c->counting, false, gb, f.stream);
                 mark(f, EV_TRACE_S);
@@ -1216,7 +1219,10 @@ int crt_render_submit(crt_ctx* c, int slot, const crt_camera* cam, const crt_par
     }
     HIPCHECK(c, hipGetLastError());
     for (int s = 0; s < spp; s++)      /* queue sizes only; the fetch counters stay on the device */
-        HIPCHECK(c, hipMemcpyAsync(f.h_ctr + (size_t)s * kCtrFetch0, f.d_ctr + (size_t)s * kCtrStride, kCtrFetch0 * 4, hipMemcpyDeviceToHost, f.stream));
+    {
+        HIPCHECK(c, hipMemcpyAsync(f.h_ctr + (size_t)s * kCtrFetch0, f.d_ctr + (size_t)s * kCtrStride, 16 * 4, hipMemcpyDeviceToHost, f.stream));
+        HIPCHECK(c, hipMemcpyAsync(f.h_ctr + (size_t)s * kCtrFetch0 + 16, f.d_ctr + (size_t)s * kCtrStride + kCtrShadow0, 16 * 4, hipMemcpyDeviceToHost, f.stream));
+    }
     HIPCHECK(c, hipMemcpyAsync(f.h_status, c->d_status, 4, hipMemcpyDeviceToHost, f.stream));
     HIPCHECK(c, hipEventRecord(f.ev_done, f.stream));
     f.in_flight = true;
