@@ -84,7 +84,7 @@ class ShardedRenderer:
     launches of one frame run in the tails of the others' persistent launches, and the gathers of finished frames run
     under the renders of later ones.  Frames complete in order, `2 * slots` calls late at most; finish() drains."""
 
-    def __init__(self, dist, torch, rank, world, local_rank, slots=3):
+    def __init__(self, dist, torch, rank, world, local_rank, slots=3, always_gather=False):
         self.dist, self.torch, self.rank, self.world = dist, torch, rank, world
         self.dev = torch.device("cuda", local_rank)
         self.ctx = api.Context(local_rank)
@@ -93,6 +93,8 @@ class ShardedRenderer:
         self._hip.hipMemcpy.restype = C.c_int
         # RCCL gathers device tensors directly; gloo (the one-GPU rehearsal) has no device gather, so stage through the host
         self.host_gather = dist.get_backend() != "nccl"
+        # always_gather: run the collective for a single rank too (the one-GPU box exercises RCCL's device gather that way)
+        self.always_gather = bool(always_gather)
         self.K = max(1, min(int(slots), api.MAX_FRAME_SLOTS - 1))      # slot 0 (the context's own stream) stays free for the unpacks
         self.frame = None
         self.frames = None          # 2K + 1 device frames, 2K packed-tile and gather buffers: see render()
@@ -219,7 +221,7 @@ class ShardedRenderer:
             self.ctx.render_wait(slot)
             self.last_stats = self.ctx.stats()
             t1 = time.perf_counter()
-            if self.world == 1:
+            if self.world == 1 and not self.always_gather:
                 done = fb
             else:
                 work, keep = self._gather(self.packs[pb], self.gathers[pb], async_op=True)
@@ -271,7 +273,7 @@ class ShardedRenderer:
             q = api.Params.from_buffer_copy(params)
             q.timing = 1                      # frame start / end events only: per-kernel intervals mean nothing between overlapping frames
             self.ctx.render_submit(slot, cam, target, q, self.frames[fb].data_ptr())
-            if self.world > 1:
+            if self.world > 1 or self.always_gather:
                 self.ctx.tiles_pack_slot(slot, q, self.frames[fb].data_ptr(), self.packs[pb].data_ptr())
             self.inflight.append((q, fb, pb, slot))
             self.seq += 1
@@ -289,7 +291,7 @@ class ShardedRenderer:
         t1 = time.perf_counter()
         if phase is not None:
             phase["render"] = phase.get("render", 0.0) + (t1 - t0)
-        if self.world == 1:
+        if self.world == 1 and not self.always_gather:
             return self.frames[0]
         self.ctx.tiles_pack(params, self.frames[0].data_ptr(), self.packs[0].data_ptr())     # returns with the copy finished
         t2 = time.perf_counter()

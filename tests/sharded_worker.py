@@ -17,8 +17,12 @@ def main():
     frames = int(sys.argv[6]) if len(sys.argv) > 6 else 0          # animation steps before the frame that is saved
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo")
-    sr = ShardedRenderer(dist, torch, rank, world, 0)
+    backend = os.environ.get("CRT_TEST_BACKEND", "gloo")      # "nccl" with WORLD_SIZE=1: RCCL's device gather on the one GPU there is
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo")
+    sr = ShardedRenderer(dist, torch, rank, world, 0, always_gather=(world == 1))
     prims = np.concatenate([crt.scene_teapot(with_sphere=True), crt.scene_soup(5000, seed=6)]) if rank == 0 else None
     if frames and rank == 0:
         prims = np.concatenate([prims, crt.scene_spheres(200, seed=8)])

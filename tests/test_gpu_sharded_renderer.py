@@ -92,3 +92,33 @@ def test_resolution_change_between_pipelined_renders(tmp_path):
             ctx.close()
         got = np.load(out)
         assert got.shape == (h2, w2, 3) and np.array_equal(got, full)
+
+
+@pytest.mark.parametrize("pipelined", [0, 1])
+def test_rccl_device_gather_on_a_one_rank_group(tmp_path, pipelined):
+    """backend "nccl" (RCCL) with one rank: the blob broadcast, the DEVICE-tensor gather (gloo stages through the host), its
+    asynchronous work handle and the wait on the collective's stream are the calls N ranks make; the frame must still be the
+    single-context frame, also after animation steps."""
+    import cudaraytracer_amd as crt
+    world, mode, w, h, bounces, frames = 1, 0, 300, 200, 2, 5
+    out = str(tmp_path / "rccl1.npy")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29561 + pipelined), WORLD_SIZE="1", RANK="0", CRT_TEST_BACKEND="nccl",
+               CRT_TEST_PIPELINED=str(pipelined))
+    p = subprocess.run([sys.executable, os.path.join(HERE, "sharded_worker.py"), out, str(w), str(h), str(bounces), str(mode), str(frames)],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout
+    prims = np.concatenate([crt.scene_teapot(with_sphere=True), crt.scene_soup(5000, seed=6), crt.scene_spheres(200, seed=8)])
+    ctx = crt.Context(0)
+    ctx.set_scene(prims); ctx.set_lights(crt.default_lights()); ctx.build(mode)
+    cam, tgt = crt.default_camera()
+    try:
+        for f in range(1, frames + 1):
+            ctx.animate_device()
+            if f % 4 == 0:
+                ctx.build(2)
+            else:
+                ctx.refit(False)
+        full = ctx.render(cam, tgt, crt.default_params(width=w, height=h, bounces=bounces))
+    finally:
+        ctx.close()
+    assert np.array_equal(np.load(out), full)
