@@ -204,7 +204,10 @@ def main():
         a.gpus = world
 
     dist = torch = None
-    if world > 1:
+    # CRT_BENCH_FORCE_DIST=1: one rank through the N > 1 code (process group, ShardedRenderer, the collectives) -- the rehearsal of
+    # the RCCL calls a one-GPU box allows; the line it prints is not a bench result
+    multi = world > 1 or bool(os.environ.get("CRT_BENCH_FORCE_DIST"))
+    if multi:
         # torch BEFORE the library: PyTorch bundles its own HIP runtime, and a process that loads libcrt_amd.so (system
         # runtime) first and torch second ends up with two runtimes, the second of which finds no device
         import torch
@@ -228,7 +231,7 @@ def main():
     log(f"scene generated: {a.tris} triangles")
 
     phase = {"render": 0.0, "pack": 0.0, "gather": 0.0, "unpack": 0.0}
-    if world > 1:
+    if multi:
         # rehearsal on a one-GPU box: CRT_DIST_BACKEND=gloo CRT_FORCE_DEVICE=0 puts every rank on one device
         backend = os.environ.get("CRT_DIST_BACKEND", "nccl")
         if "CRT_FORCE_DEVICE" in os.environ:
@@ -239,7 +242,7 @@ def main():
         else:
             dist.init_process_group(backend)
         from cudaraytracer_amd.parallel import ShardedRenderer
-        sr = ShardedRenderer(dist, torch, rank, world, local_rank, slots=a.slots)
+        sr = ShardedRenderer(dist, torch, rank, world, local_rank, slots=a.slots, always_gather=(world == 1))
         sr.broadcast_scene(prims, lights, a.bvh)
         ctx = sr.ctx
 
@@ -285,14 +288,14 @@ def main():
            "ms_other": 0.0, "launches_trace_nearest": 0, "launches_trace_shadow": 0, "launches_trace_mixed": 0}
     for _ in range(a.steps):
         step()
-        if world == 1:
+        if not multi:
             st = ctx.stats()
             for k in acc:
                 acc[k] += st[k]
     fence()
     elapsed = time.perf_counter() - t0
     log(f"timed steps done: {elapsed / a.steps * 1e3:.3f} ms/step")
-    if world > 1:
+    if multi:
         # N > 1 keeps several frames in flight per rank (frame slots): the intervals between per-kernel events then hold other
         # frames' kernels too.  The per-kernel figures (frame_ms_split_rank0, the roofline's launch duration) come from this
         # rank's frames rendered one at a time, after the timed region, with HIP events around every kernel
@@ -305,7 +308,7 @@ def main():
 
     rays = np.array([st["rays_primary"], st["rays_shadow"], st["rays_reflect"]], np.float64)
     per_rank = None
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -490,12 +493,14 @@ def main():
             },
             "roofline": roof,
         }
+        if multi and world == 1:
+            out["config"]["rehearsal"] = "CRT_BENCH_FORCE_DIST: one rank through the N > 1 code path (backend %s); not a bench result" % dist.get_backend()
         if per_rank is not None:
             out["config"]["per_rank_ms"] = {"columns": ["device_render_one_frame_alone", "host_wait_for_render", "host_submit_and_pack_launch", "gather_issue", "gather_wait_and_unpack"],
                                             "ranks": per_rank}
             out["config"]["frames_in_flight_per_rank"] = 1 if a.no_pipeline else sr.K
             out["config"]["per_kernel_times"] = "this rank's frames rendered one at a time after the timed region (frames in flight overlap each other's kernels)"
-        if world == 1:
+        if not multi:
             # the PCIe-inclusive frame (crt_render: same kernels + device->host copy of the BGR frame);
             # reported beside, never as, `value`
             ctx.render(cam, tgt, params)
@@ -503,7 +508,7 @@ def main():
             for _ in range(3):
                 ctx.render(cam, tgt, params)
             out["config"]["frame_ms_with_d2h_copy"] = round((time.perf_counter() - t1) / 3 * 1e3, 4)
-        if world == 1 and a.frames_in_flight:
+        if not multi and a.frames_in_flight:
             # throughput with several frames in flight on the context's frame slots (crt_render_submit / crt_render_wait): the
             # launches of one frame run in the tails of the other frames' persistent launches.  Beside `value`, which keeps
             # one frame complete before the next starts (its per-kernel times are what the roofline prices)
@@ -529,9 +534,9 @@ def main():
             ms_pipe = (time.perf_counter() - t1) / (4 * K) * 1e3
             out["config"]["frames_in_flight"] = {"slots": K, "ms_per_frame": round(ms_pipe, 4), "mrays_per_s": round(total_rays / ms_pipe / 1e3, 1),
                                                  "note": "same frames, same kernels, frames in flight on frame slots 1..K; not `value`"}
-        if a.out_bmp and world == 1:
+        if a.out_bmp and not multi:
             crt.write_bmp(a.out_bmp, ctx.render(cam, tgt, params), fw, fh)
-        if world == 1 and a.bvh != 2:
+        if not multi and a.bvh != 2:
             # the same scene rebuilt ON THE DEVICE (lbvh.hip + refrank.hip: wide LBVH with the reference's
             # tie-break ranks), after the timed region: its build time, and the frame time on that tree
             c2 = crt.Context(local_rank)
@@ -554,12 +559,12 @@ def main():
                                                       "tie_break": "reference leaf order, replayed on the device"}
             finally:
                 c2.close()
-        if world == 1 and not a.no_cpu_baseline:
+        if not multi and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prims, lights, cam, tgt, fw, fh, a.bounces, a.cpu_threads)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
