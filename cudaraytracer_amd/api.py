@@ -45,7 +45,7 @@ class Params(C.Structure):
                 ("tile_w", C.c_int32), ("tile_h", C.c_int32), ("rank", C.c_int32), ("nranks", C.c_int32),
                 ("sort_rays", C.c_int32), ("area_samples", C.c_int32), ("use_graph", C.c_int32),
                 ("tile_sub", C.c_int32), ("tile_nsub", C.c_int32), ("grid_div", C.c_int32), ("timing", C.c_int32),
-                ("reserved", C.c_int32 * 1)]
+                ("zero_paths", C.c_int32)]
 
 
 class Stats(C.Structure):

@@ -57,7 +57,7 @@ struct FrameSlot {
      * contents changes */
     struct GraphKey {
         crt_camera cam; crt_params p; LightsParam lights;
-        const void* ptrs[20]; uint32_t nnodes, nprims, nmats, depth, mode; int counting, capture, grid, ovf_depth, block; float scene_abs;
+        const void* ptrs[20]; uint32_t nnodes, nprims, nmats, depth, mode; int counting, capture, grid, ovf_depth, block, keep_zero; float scene_abs;
     };
     GraphKey graph_key{}; hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; bool in_capture = false;
     uint8_t* d_bgr = nullptr; size_t bgr_cap = 0;
@@ -98,6 +98,9 @@ struct crt_ctx {
     HostBVH bvh;
     bool built = false, have_ref = false, imported = false;
     bool host_stale = false;     /* crt_animate_device moved the device copy of the scene past c->prims */
+    /* can a shading term of this scene / these lights be non-finite?  Decides whether paths with a zero coefficient may end
+     * (crt_params.zero_paths = 0); the scene's half travels in BlobHeader.flags */
+    bool nonfinite_scene = false, nonfinite_lights = false;
 
     /* packed scene */
     void* d_blob = nullptr; size_t blob_bytes = 0; size_t blob_cap = 0;
@@ -184,6 +187,47 @@ SceneView view_of(const crt_ctx* c) {
     v.mats = (const Material*)(b + c->hdr.off_mats);
     v.nprims = c->hdr.nprims; v.nnodes = c->hdr.nnodes;
     return v;
+}
+
+/* crt_params.zero_paths: a path whose coefficient is (0,0,0) may end iff nothing it could still add -- coefficient * colour,
+ * Ray.cu:660 -- can be non-finite.  Sufficient conditions on the scene, each one a way the reference's Shade (Ray.cu:546-663)
+ * or its normals (Ray.cu:135,168-172) produce NaN or infinity from finite rays:
+ *   - a material value that is not finite; a shininess that is negative (pow(0, s) = inf), fractional (pow of a negative
+ *     base = NaN, Ray.cu:655) or beyond 1e6 (|base| may exceed 1 by a rounding);
+ *   - a sphere of radius <= 0 ((X - c) / r, Ray.cu:135);
+ *   - a triangle whose vertex normals are not finite or do not all lie strictly on one side of its plane: their
+ *     barycentric mix can then be the zero vector, and normalize(0) is NaN (Ray.cu:172).  Zero-area triangles are never hit. */
+static bool finite3(const float* v) { return v[0] * 0.f + v[1] * 0.f + v[2] * 0.f == 0.f; }
+bool shading_may_be_nonfinite(const std::vector<crt_prim>& prims) {
+    for (const crt_prim& p : prims) {
+        if (!finite3(p.ambient) || !finite3(p.diffuse) || !finite3(p.specular) || !finite3(p.reflective)) return true;
+        const float s = p.shininess;
+        if (!(s >= 0.f && s <= 1e6f) || s != floorf(s)) return true;
+        if (p.type == 0) { if (!(p.radius > 0.f)) return true; continue; }
+        const vec3 v1(p.v1), v2(p.v2), v3(p.v3);
+        const vec3 g = cross(v2 - v1, v3 - v1);
+        if (!(dot(g, g) > 0.f)) continue;
+        if (!finite3(p.v1Norm) || !finite3(p.v2Norm) || !finite3(p.v3Norm)) return true;
+        const float a = dot(vec3(p.v1Norm), g), b = dot(vec3(p.v2Norm), g), d = dot(vec3(p.v3Norm), g);
+        if (!((a > 0.f && b > 0.f && d > 0.f) || (a < 0.f && b < 0.f && d < 0.f))) return true;
+    }
+    return false;
+}
+bool lights_may_be_nonfinite(const LightsParam& L) {
+    for (int i = 0; i < L.n; i++) {
+        const crt_light& l = L.l[i];
+        if (!finite3(l.color)) return true;
+        if (l.area || l.point) {
+            if (!finite3(l.position)) return true;
+            if (l.area) { if (!(l.radius * 0.f == 0.f)) return true; }
+            else if (!(l.constantTerm * 0.f + l.linearTerm * 0.f + l.quadraticTerm * 0.f == 0.f)) return true;
+        } else {
+            if (!finite3(l.direction)) return true;
+            const float n2 = l.direction[0] * l.direction[0] + l.direction[1] * l.direction[1] + l.direction[2] * l.direction[2];
+            if (!(n2 > 0.f) || !(n2 * 0.f == 0.f)) return true;          /* normalize(direction), Ray.cu:635-636 */
+        }
+    }
+    return false;
 }
 
 void dedupe_materials(crt_ctx* c) {
@@ -570,6 +614,7 @@ int crt_scene_set(crt_ctx* c, const crt_prim* prims, int n) {
     { const int rc = drain_frames(c); if (rc) return rc; }
     c->prims.assign(prims, prims + n);
     dedupe_materials(c);
+    c->nonfinite_scene = shading_may_be_nonfinite(c->prims);
     c->built = false; c->have_ref = false; c->imported = false; c->host_stale = false;
     return upload_prims(c);
 }
@@ -594,6 +639,12 @@ int crt_scene_update(crt_ctx* c, const crt_prim* prims, int n) {
     }
     int rc = upload_prims(c);
     if (rc) return rc;
+    c->nonfinite_scene = shading_may_be_nonfinite(c->prims);          /* radii and normals moved */
+    if (c->built && ((c->hdr.flags & kBlobNonFiniteShading) != 0u) != c->nonfinite_scene) {
+        c->hdr.flags = (c->hdr.flags & ~kBlobNonFiniteShading) | (c->nonfinite_scene ? kBlobNonFiniteShading : 0u);
+        HIPCHECK(c, hipMemcpyAsync((char*)c->d_blob + offsetof(BlobHeader, flags), &c->hdr.flags, 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(c, hipStreamSynchronize(c->stream));      /* the source is a member of the context, not pinned memory */
+    }
     if (c->built) {
         char* b = (char*)c->d_blob;
         launch_pack_prims(c->d_prims, c->d_matid, (const uint32_t*)(b + c->hdr.off_slot_of), (uint32_t)n,
@@ -641,6 +692,7 @@ int crt_lights_set(crt_ctx* c, const crt_light* lights, int n) {
     memset(&c->lights, 0, sizeof c->lights);
     for (int i = 0; i < n; i++) c->lights.l[i] = lights[i];
     c->lights.n = n;
+    c->nonfinite_lights = lights_may_be_nonfinite(c->lights);
     return CRT_OK;
 }
 
@@ -682,7 +734,7 @@ static int device_build_core(crt_ctx* c, DevBuild& B, std::string& err) {
     }
     BlobHeader h{};
     h.magic = kBlobMagic; h.version = kBlobVersion;
-    h.nprims = n; h.nnodes = nnodes; h.nmats = (uint32_t)c->mats.size();
+    h.nprims = n; h.nnodes = nnodes; h.nmats = (uint32_t)c->mats.size(); h.flags = c->nonfinite_scene ? kBlobNonFiniteShading : 0u;
     h.depth = depth; h.mode = CRT_BVH_WIDE;
     memcpy(h.root_box, root_box, sizeof h.root_box);
     layout_blob(h);
@@ -775,7 +827,7 @@ int crt_bvh_build(crt_ctx* c, int mode) {
 
     BlobHeader h{};
     h.magic = kBlobMagic; h.version = kBlobVersion;
-    h.nprims = (uint32_t)n; h.nnodes = (uint32_t)c->bvh.node_count(); h.nmats = (uint32_t)c->mats.size();
+    h.nprims = (uint32_t)n; h.nnodes = (uint32_t)c->bvh.node_count(); h.nmats = (uint32_t)c->mats.size(); h.flags = c->nonfinite_scene ? kBlobNonFiniteShading : 0u;
     h.depth = (uint32_t)c->bvh.depth; h.mode = (uint32_t)mode;
     memcpy(h.root_box, c->bvh.root_box, sizeof h.root_box);
     layout_blob(h);
@@ -1003,6 +1055,8 @@ static int fill_frame_params(crt_ctx* c, const crt_camera* cam, const crt_params
     fp.width = p->width; fp.height = p->height; fp.tile_w = p->tile_w; fp.tile_h = p->tile_h;
     fp.tiles_x = (p->width + p->tile_w - 1) / p->tile_w;
     fp.spp_n = sn; fp.bounces = p->bounces; fp.capture = c->capture ? 1 : 0;
+    if (p->zero_paths < 0 || p->zero_paths > 2) return fail(c, CRT_ERR_ARG, "render: zero_paths must be 0 (automatic), 1 (trace on) or 2 (end)");
+    fp.keep_zero = p->zero_paths == 1 || (p->zero_paths == 0 && (c->nonfinite_scene || c->nonfinite_lights)) ? 1 : 0;
     return CRT_OK;
 }
 
@@ -1201,7 +1255,7 @@ int crt_render_submit(crt_ctx* c, int slot, const crt_camera* cam, const crt_par
                                 c->d_area_table, f.sum};
         memcpy(key.ptrs, ptrs, sizeof ptrs);
         key.nnodes = c->hdr.nnodes; key.nprims = c->hdr.nprims; key.nmats = c->hdr.nmats; key.depth = c->hdr.depth; key.mode = c->hdr.mode;
-        key.counting = c->counting; key.capture = c->capture; key.grid = gb; key.ovf_depth = c->ovf_depth; key.block = c->trace_block; key.scene_abs = sabs;
+        key.counting = c->counting; key.capture = c->capture; key.grid = gb; key.ovf_depth = c->ovf_depth; key.block = c->trace_block; key.keep_zero = fp.keep_zero; key.scene_abs = sabs;
         if (!f.graph_exec || memcmp(&key, &f.graph_key, sizeof key) != 0) {
             if (f.graph_exec) { hipGraphExecDestroy(f.graph_exec); f.graph_exec = nullptr; }
             if (f.graph) { hipGraphDestroy(f.graph); f.graph = nullptr; }
@@ -1514,6 +1568,7 @@ int crt_blob_import_device(crt_ctx* c, const void* dev_ptr, size_t bytes) {
      * multi-GPU run) keeps its crt_prim array and material ids, so crt_animate_device / crt_scene_update /
      * crt_bvh_refit / crt_bvh_build work on it as on the rank that built the blob */
     c->blob_bytes = bytes; c->hdr = h; c->built = true; c->imported = c->prims.size() != (size_t)h.nprims;
+    c->nonfinite_scene = (h.flags & kBlobNonFiniteShading) != 0u;
     c->have_ref = c->have_ref && dev_ptr == c->d_blob;
     int rc = ensure(c, c->d_arrive, c->arrive_cap, (size_t)h.nnodes + 1);
     if (rc) return rc;

@@ -76,6 +76,7 @@ struct FrameParams {
     int32_t spp_n, sample;            /* spp = spp_n^2; sample in [0, spp) */
     int32_t bounce, bounces;
     int32_t capture;
+    int32_t keep_zero;                /* emit the next ray of a path whose coefficient is (0,0,0) too (crt_params.zero_paths) */
 };
 
 /* Shade treats every light as one or more SLOTS: a directional or point light owns one, an area light one per

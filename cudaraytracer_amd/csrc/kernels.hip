@@ -1481,7 +1481,9 @@ __global__ CRT_SHADE_BOUNDS void k_shade(FrameParams P, FrameBuffers B, SceneVie
         }
 
         /* ---- reserve queue space: count this block's shadow and reflection rays ---- */
-        const bool emit = !dead && (P.bounce + 1 < P.bounces) && (newcoef.x != 0.f || newcoef.y != 0.f || newcoef.z != 0.f);
+        /* a path whose coefficient is (0,0,0) adds 0 * colour from here on: it ends, unless a later colour could be non-finite
+         * (0 * NaN is NaN in Ray.cu:660) -- P.keep_zero, decided per scene on the host (crt_params.zero_paths) */
+        const bool emit = !dead && (P.bounce + 1 < P.bounces) && (P.keep_zero != 0 || newcoef.x != 0.f || newcoef.y != 0.f || newcoef.z != 0.f);
         uint32_t wave_sh = 0;
         for (int j = 0; j < LP.n; j++) {
             bool want = false;

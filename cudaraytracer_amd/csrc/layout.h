@@ -106,8 +106,11 @@ struct BlobHeader {
     uint64_t off_nodes, off_qnodes, off_geom, off_shade, off_rank, off_sidx, off_slot_of, off_mats;
     uint64_t total_bytes;
     float root_box[6];        /* minX,maxX,minY,maxY,minZ,maxZ written by build and refit */
-    uint32_t pad[8];
+    uint32_t flags;           /* bit 0 (kBlobNonFiniteShading): the scene can shade to a non-finite colour, so paths whose coefficient
+                               * is zero are traced on (crt_params.zero_paths); travels with the blob to the ranks that import it */
+    uint32_t pad[7];
 };
+constexpr uint32_t kBlobNonFiniteShading = 1u;
 static_assert(sizeof(BlobHeader) % 16 == 0, "header alignment");
 
 /* Device-side view: raw pointers into the blob. */

@@ -85,7 +85,14 @@ typedef struct crt_params {
     int32_t grid_div;        /* > 1: the persistent traversal grid is the chip's resident capacity divided by this (frames in
                               * flight on several slots share the chip side by side instead of taking turns).  0 */
     int32_t timing;          /* 0: HIP events around every kernel (crt_stats ms_trace, ms_shade ...); 1: frame start / end only */
-    int32_t reserved[1];
+    int32_t zero_paths;      /* paths whose reflection coefficient has become exactly (0,0,0) -- every path after a wall, Ray.cu:257,262,
+                              * or after a material that reflects nothing.  The reference traces them on and adds 0 * colour
+                              * (Ray.cu:660, 715-723), which changes the pixel only when that colour is not finite (pow of a
+                              * negative base with a fractional shininess, a zero-length normal ...): the pixel then turns NaN.
+                              * 0: end such paths when the scene and the lights cannot produce a non-finite term (materials finite
+                              * with an integral shininess in [0, 1e6], sphere radii > 0, vertex normals on one side of their
+                              * triangle, lights finite with a direction), trace them on otherwise -- the image is the reference's
+                              * either way; 1: always trace them on (the reference's ray count); 2: always end them */
 } crt_params;
 
 typedef struct crt_stats {

@@ -51,8 +51,7 @@ def compare(crt, prims, rays, what, modes=(0, 2), min_hits=100):
         rel = np.abs(ts_g[hit] - ts_o[hit]) / np.maximum(np.abs(ts_o[hit]), 1e-30)
         print(f"{what} mode={mode}: rays={len(rays)} hits={int((ids_o >= 0).sum())} id_mismatch={int(bad.sum())} "
               f"t_exact={int((ts_g[hit] == ts_o[hit]).sum())}/{int(hit.sum())}")
-        # the device build (mode 2) has no reference-order pass: exact-t ties may resolve differently there
-        assert bad.sum() <= (2 if mode != 2 else max(2, len(rays) // 5000)), f"{what} mode={mode}: {int(bad.sum())} id mismatches"
+        assert bad.sum() <= 2, f"{what} mode={mode}: {int(bad.sum())} id mismatches"
         assert (rel > T_RTOL).sum() == 0
 
 
