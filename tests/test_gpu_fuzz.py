@@ -220,3 +220,192 @@ def test_zero_paths_parameter(crt):
     for z in (0, 1, 2):
         assert np.array_equal(frames[z], o["bgr"]), f"zero_paths={z}"
     assert rays[1] == ost["traversals"] and rays[0] == rays[2] == ost["live_traversals"], (rays, ost)
+
+
+def _hip():
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    return hip, C
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_random_animation_loop_on_frame_slots_equals_the_oracle(crt, seed):
+    """the reference's loop (main.cu:534-573: move, refit or rebuild, render) with every choice drawn from the seed: tight or
+    grow-only refit, host / device / asynchronous rebuild, host-side or device-side animation step, the frame rendered
+    synchronously or submitted on one of the frame slots and collected up to three steps later -- after the scene has moved on.
+    Every frame must be the oracle's frame of the scene as it was when the frame was submitted."""
+    rng = np.random.default_rng(9000 + seed)
+    prims = random_scene(crt, rng)
+    n = len(prims)
+    prims["direction"] = rng.normal(size=(n, 3)).astype(np.float32)
+    prims["speed"] = rng.uniform(0, 1.5, n).astype(np.float32)
+    prims["shininess"] = np.floor(prims["shininess"])          # frames of both kinds (zero_paths) are covered above; keep this one fast
+    lights = random_lights(crt, rng)
+    lights = lights[[not l["area"] for l in lights]] if len(lights) else lights
+    w, h, bounces = int(rng.integers(60, 160)), int(rng.integers(40, 100)), int(rng.integers(1, 4))
+    cam = rng.uniform(-150, 150, 3).astype(np.float32)
+    tgt = rng.uniform(-40, 40, 3).astype(np.float32)
+    p = crt.default_params(width=w, height=h, bounces=bounces)
+    hip, C = _hip()
+    nbytes = w * h * 3
+    bufs = []
+    for _ in range(4):
+        q = C.c_void_p(0)
+        assert hip.hipMalloc(C.byref(q), nbytes) == 0
+        bufs.append(q.value)
+    sc = orc.Scene(prims); sc.build()
+    ctx = crt.Context(0)
+    pending = {}          # slot -> (step it was submitted at, the oracle's frame of that step)
+    host = prims.copy()
+    log = []
+
+    def collect(slot):
+        step0, want = pending.pop(slot)
+        ctx.render_wait(slot)
+        got = np.zeros(nbytes, np.uint8)
+        assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), bufs[slot], nbytes, 2) == 0
+        assert np.array_equal(got.reshape(h, w, 3), want), f"seed {seed}: frame submitted at step {step0} on slot {slot}; log: {log}"
+
+    try:
+        ctx.set_scene(prims); ctx.set_lights(lights); ctx.build(int(rng.choice([0, 2])))
+        building = False
+        for step in range(14):
+            # ---- move the scene
+            on_device = bool(rng.integers(0, 2)) and not building       # crt_scene_update during an asynchronous build is fine too, but keep the host copy in step
+            crt.animate_host(host); sc.animate()
+            if on_device:
+                ctx.animate_device()
+            else:
+                if rng.integers(0, 2):
+                    ctx.animate_device()          # the device moves it ...
+                    ctx.update_scene(host)        # ... and the host overwrites it with the same bytes
+                else:
+                    ctx.update_scene(host)
+            # ---- refit or rebuild
+            kind = int(rng.choice([0, 0, 0, 1, 2, 3, 4]))
+            if building:
+                kind = 5 if rng.integers(0, 2) else 0
+            if kind == 0: ctx.refit(False)
+            elif kind == 1: ctx.refit(True)
+            elif kind == 2: ctx.build(2)
+            elif kind == 3:
+                for s in list(pending): collect(s)          # crt_scene_set waits for the frames in flight itself; collect them first so their buffers are compared
+                ctx.set_scene(host); ctx.build(0)
+            elif kind == 4:
+                ctx.build_async(); building = True; ctx.refit(False)
+            elif kind == 5:
+                if ctx.swap(wait=True): building = False
+                else: ctx.refit(False)
+            log.append((step, "dev" if on_device else "host", kind))
+            sc.refit()
+            # ---- render
+            want = sc.render(lights, cam, tgt, w, h, bounces, nthreads=16)["bgr"]
+            slot = int(rng.integers(0, 4))
+            if slot == 0 and rng.integers(0, 2):
+                if 0 in pending: collect(0)          # crt_render is submit + wait on slot 0
+                got = ctx.render(cam, tgt, p)
+                assert np.array_equal(got, want), f"seed {seed}: synchronous frame at step {step}; log: {log}"
+            else:
+                if slot in pending: collect(slot)
+                ctx.render_submit(slot, cam, tgt, p, bufs[slot])
+                pending[slot] = (step, want)
+            for s in [s for s, (st0, _) in pending.items() if step - st0 >= 3]:
+                collect(s)
+        for s in list(pending):
+            collect(s)
+        assert ctx.get_scene().tobytes() == host.tobytes()
+    finally:
+        ctx.close(); sc.close()
+        for q in bufs:
+            hip.hipFree(C.c_void_p(q))
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_random_sharding_equals_the_oracle(crt, seed):
+    """SURVEY 8(e) with everything drawn from the seed: 1..8 logical ranks in one process (crt_mgpu_*), tile sizes other than
+    32 x 32, frames the tiles do not divide, scenes that trace zero-coefficient paths on (the flag reaches the other ranks in
+    the blob header only).  The gathered frame is the oracle's frame and the ranks together issue the oracle's traversals."""
+    rng = np.random.default_rng(7000 + seed)
+    prims = random_scene(crt, rng)
+    lights = random_lights(crt, rng)
+    world = int(rng.integers(1, 9))
+    w, h = int(rng.integers(40, 260)), int(rng.integers(30, 170))
+    tw, th = int(rng.choice([8, 16, 32, 64])), int(rng.choice([8, 16, 32, 64]))
+    bounces = int(rng.integers(1, 4))
+    spp = int(rng.choice([1, 1, 4]))
+    area_samples = int(rng.integers(1, 6))
+    cam = rng.uniform(-150, 150, 3).astype(np.float32)
+    tgt = rng.uniform(-40, 40, 3).astype(np.float32)
+    sc = orc.Scene(prims); sc.build()
+    try:
+        sc.stats(reset=True)
+        o = sc.render(lights, cam, tgt, w, h, bounces, nthreads=16, area_samples=area_samples, spp=spp)
+        ost = sc.stats(reset=True)
+    finally:
+        sc.close()
+    fractional = bool((prims["shininess"] != np.floor(prims["shininess"])).any())
+    p = crt.default_params(width=w, height=h, bounces=bounces, spp=spp, area_samples=area_samples, tile_w=tw, tile_h=th)
+    m = crt.MultiGpu([0] * world)
+    try:
+        m.root.set_scene(prims); m.root.build(int(rng.choice([0, 2]))); m.set_lights(lights); m.sync_scene()
+        got = m.render(cam, tgt, p)
+        rays = sum(m.rank_stats(r)["rays_primary"] + m.rank_stats(r)["rays_shadow"] + m.rank_stats(r)["rays_reflect"] for r in range(world))
+    finally:
+        m.close()
+    what = f"seed {seed}: {world} ranks, {w}x{h}, tiles {tw}x{th}, bounces={bounces}, spp={spp}, {len(prims)} prims, {len(lights)} lights"
+    diff = np.abs(got.astype(np.int32) - o["bgr"].astype(np.int32)).max(axis=2)
+    print(f"{what}: exact={int((diff == 0).sum())}/{w * h} rays={rays} oracle={ost['traversals']} live={ost['live_traversals']}")
+    assert int((diff > 0).sum()) == 0, what
+    assert rays == (ost["traversals"] if fractional else ost["live_traversals"]), what
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_random_scenes_with_coincident_primitives(crt, seed):
+    """exact-t ties everywhere: a third of the primitives are bit-identical copies of other primitives with other materials,
+    scattered through the scene order, so that the hit id -- and through the material the pixel -- depends on which copy the
+    reference's traversal meets first (Ray.cu:184-236: leaf order of bvh.cu's tree, strict '<').  All three trees must
+    reproduce that order (the device-built one replays it, refrank.hip)."""
+    rng = np.random.default_rng(11000 + seed)
+    base = random_scene(crt, rng)
+    n = len(base)
+    k = max(1, n // 2)
+    src = rng.integers(0, n, k)
+    dup = base[src].copy()
+    dup["diffuse"] = rng.uniform(0, 1, (k, 3)).astype(np.float32)
+    dup["reflective"] = rng.uniform(0, 1, (k, 3)).astype(np.float32)
+    dup["shininess"] = np.float32(3.0)
+    prims = np.concatenate([base, dup])
+    prims["shininess"] = np.floor(prims["shininess"])
+    prims = np.ascontiguousarray(prims[rng.permutation(len(prims))])
+    prims["objNum"] = np.arange(len(prims), dtype=np.int32)
+    lights = random_lights(crt, rng)
+    w, h, bounces = int(rng.integers(60, 200)), int(rng.integers(40, 120)), int(rng.integers(1, 4))
+    cam = rng.uniform(-150, 150, 3).astype(np.float32)
+    tgt = rng.uniform(-40, 40, 3).astype(np.float32)
+    sc = orc.Scene(prims); sc.build()
+    try:
+        o = sc.render(lights, cam, tgt, w, h, bounces, nthreads=16, want_color=True, want_ids=True)
+    finally:
+        sc.close()
+    for mode in (0, 1, 2):
+        ctx = crt.Context(0)
+        try:
+            ctx.set_scene(prims); ctx.set_lights(lights)
+            try:
+                ctx.build(mode)
+            except crt.CrtError:
+                assert mode == 1
+                continue
+            ctx.set_capture(True)
+            g = ctx.render(cam, tgt, crt.default_params(width=w, height=h, bounces=bounces))
+            for b in range(bounces):
+                ids_g, _ = ctx.capture(b, w * h)
+                traced = ids_g != -9
+                bad = int((ids_g[traced] != o["ids"][b][traced]).sum())
+                assert bad == 0, f"seed {seed} mode {mode} bounce {b}: {bad} of {int(traced.sum())} hit ids differ"
+            assert np.array_equal(g, o["bgr"]), f"seed {seed} mode {mode}"
+        finally:
+            ctx.close()
