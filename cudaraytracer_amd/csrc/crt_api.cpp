@@ -192,15 +192,18 @@ SceneView view_of(const crt_ctx* c) {
 /* crt_params.zero_paths: a path whose coefficient is (0,0,0) may end iff nothing it could still add -- coefficient * colour,
  * Ray.cu:660 -- can be non-finite.  Sufficient conditions on the scene, each one a way the reference's Shade (Ray.cu:546-663)
  * or its normals (Ray.cu:135,168-172) produce NaN or infinity from finite rays:
- *   - a material value that is not finite; a shininess that is negative (pow(0, s) = inf), fractional (pow of a negative
+ *   - a material value that is not finite or beyond 1e9 in magnitude (sums of products may overflow; light colours likewise); a shininess that is negative (pow(0, s) = inf), fractional (pow of a negative
  *     base = NaN, Ray.cu:655) or beyond 1e6 (|base| may exceed 1 by a rounding);
  *   - a sphere of radius <= 0 ((X - c) / r, Ray.cu:135);
  *   - a triangle whose vertex normals are not finite or do not all lie strictly on one side of its plane: their
  *     barycentric mix can then be the zero vector, and normalize(0) is NaN (Ray.cu:172).  Zero-area triangles are never hit. */
 static bool finite3(const float* v) { return v[0] * 0.f + v[1] * 0.f + v[2] * 0.f == 0.f; }
+/* finite and small enough that sums and products of a few of them cannot overflow: a colour is at most
+ * 8 lights x 1.5 x lcolor x (.6 diffuse + .2 specular (1 + 1e-6)^shininess) */
+static bool tame3(const float* v) { return fabsf(v[0]) <= 1e9f && fabsf(v[1]) <= 1e9f && fabsf(v[2]) <= 1e9f; }
 bool shading_may_be_nonfinite(const std::vector<crt_prim>& prims) {
     for (const crt_prim& p : prims) {
-        if (!finite3(p.ambient) || !finite3(p.diffuse) || !finite3(p.specular) || !finite3(p.reflective)) return true;
+        if (!tame3(p.ambient) || !tame3(p.diffuse) || !tame3(p.specular) || !finite3(p.reflective)) return true;
         const float s = p.shininess;
         if (!(s >= 0.f && s <= 1e6f) || s != floorf(s)) return true;
         if (p.type == 0) { if (!(p.radius > 0.f)) return true; continue; }
@@ -216,7 +219,7 @@ bool shading_may_be_nonfinite(const std::vector<crt_prim>& prims) {
 bool lights_may_be_nonfinite(const LightsParam& L) {
     for (int i = 0; i < L.n; i++) {
         const crt_light& l = L.l[i];
-        if (!finite3(l.color)) return true;
+        if (!tame3(l.color)) return true;
         if (l.area || l.point) {
             if (!finite3(l.position)) return true;
             if (l.area) { if (!(l.radius * 0.f == 0.f)) return true; }

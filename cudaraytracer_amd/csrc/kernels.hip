@@ -1463,7 +1463,9 @@ __global__ CRT_SHADE_BOUNDS void k_shade(FrameParams P, FrameBuffers B, SceneVie
                         B.accum[pix] = make_float4(c0.x, c0.y, c0.z, 0.f);
                         rc = vec3(1.0f, 1.0f, 1.0f);
                     } else rc = cin;
-                    newcoef = vec3(0.f, 0.f, 0.f);        /* Ray.cu:257,262: nothing is reflected off a wall */
+                    /* Ray.cu:257,262: nothing is reflected off a wall -- literally zero behind a primary ray, coefficient * 0 behind a
+                     * reflected one, which is NaN once the coefficient has overflowed (reflective > 1 compounds) and keeps the path alive */
+                    newcoef = raytype == 0 ? vec3(0.f, 0.f, 0.f) : cin * vec3(0.f, 0.f, 0.f);
                     incident = normalize(reflect(d, N));
                     diffuse = vec3(c_walls[w].diffuse); specular = vec3(0.f, 0.f, 0.f); shininess = 2;
                     cap_id = -2 - w;
@@ -1558,8 +1560,9 @@ __global__ CRT_SHADE_BOUNDS void k_shade(FrameParams P, FrameBuffers B, SceneVie
                                         const float spec = powf_libm(sdot, shininess, s_ltab, s_etab);
                     const vec3 X = (.6f * diffuse * gmax(dot(toLight, N), 0.0f) + .2f * specular * spec);
                     /* a light that is shadowed without a ray contributes distance * 0 * lcolor * X (Ray.cu:629,655): exactly zero
-                     * unless X is not finite, so the 16-byte record is written only where Ray.cu:660 can see it */
-                    if (flag && X.x - X.x == 0.f && X.y - X.y == 0.f && X.z - X.z == 0.f) flag = kShNoContribution;
+                     * unless X or the light's colour is not finite, so the 16-byte record is written only where Ray.cu:660 can see it */
+                    const bool lfinite = l.color[0] * 0.f + l.color[1] * 0.f + l.color[2] * 0.f == 0.f;
+                    if (flag && lfinite && X.x - X.x == 0.f && X.y - X.y == 0.f && X.z - X.z == 0.f) flag = kShNoContribution;
                     else B.contrib[plane] = make_float4(X.x, X.y, X.z, distance);
                     B.shflag[plane] = flag;
                 } else if (valid) B.shflag[plane] = kShDeadPath;
