@@ -461,11 +461,15 @@ void export_nodes(const std::vector<N>& nodes, float* child_boxes, uint32_t* chi
 
 namespace {
 /* the builders and the refit assume finite boxes: a NaN or infinite coordinate is an argument error, not a scene */
+/* coordinates must be finite and radii >= 0.  A negative radius is not an error in the reference: intersectSphere squares it
+ * (Ray.cu:110) while the boxes of bvh.cu come out inverted (centre - r > centre + r), so whether a ray ever reaches the sphere
+ * depends on what else shares its 64-primitive leaf -- a property of that one tree, which no other tree can reproduce.
+ * Rejected here instead (CRT_ERR_ARG). */
 bool finite_geometry(const crt_prim* prims, int n) {
     for (int i = 0; i < n; i++) {
         const crt_prim& p = prims[i];
         float acc = 0.f;          /* x * 0 is 0 for every finite x and NaN otherwise */
-        if (p.type == 0) acc = p.position[0] * 0.f + p.position[1] * 0.f + p.position[2] * 0.f + p.radius * 0.f;
+        if (p.type == 0) { acc = p.position[0] * 0.f + p.position[1] * 0.f + p.position[2] * 0.f + p.radius * 0.f; if (p.radius < 0.f) return false; }
         else for (int k = 0; k < 3; k++) acc += p.v1[k] * 0.f + p.v2[k] * 0.f + p.v3[k] * 0.f;
         if (!(acc == 0.f)) return false;
     }
@@ -611,7 +615,7 @@ int crt_scene_set(crt_ctx* c, const crt_prim* prims, int n) {
     if (n > CRT_MAX_PRIMS) return fail(c, CRT_ERR_ARG, "crt_scene_set: too many primitives");
     for (int i = 0; i < n; i++)
         if (prims[i].type != 0 && prims[i].type != 1) return fail(c, CRT_ERR_ARG, "crt_scene_set: type must be 0 (sphere) or 1 (triangle)");
-    if (!finite_geometry(prims, n)) return fail(c, CRT_ERR_ARG, "crt_scene_set: non-finite coordinate");
+    if (!finite_geometry(prims, n)) return fail(c, CRT_ERR_ARG, "crt_scene_set: non-finite coordinate or negative radius");
     HIPCHECK(c, hipSetDevice(c->device));
     cancel_async_build(c);
     { const int rc = drain_frames(c); if (rc) return rc; }
@@ -628,7 +632,7 @@ int crt_scene_update(crt_ctx* c, const crt_prim* prims, int n) {
     if ((size_t)n != c->prims.size()) return fail(c, CRT_ERR_ARG, "crt_scene_update: count differs from crt_scene_set");
     for (int i = 0; i < n; i++)
         if (prims[i].type != c->prims[i].type) return fail(c, CRT_ERR_ARG, "crt_scene_update: primitive type changed");
-    if (!finite_geometry(prims, n)) return fail(c, CRT_ERR_ARG, "crt_scene_update: non-finite coordinate");
+    if (!finite_geometry(prims, n)) return fail(c, CRT_ERR_ARG, "crt_scene_update: non-finite coordinate or negative radius");
     HIPCHECK(c, hipSetDevice(c->device));
     { const int rc = order_after_frames(c); if (rc) return rc; }
     c->host_stale = false;

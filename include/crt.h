@@ -140,7 +140,10 @@ void crt_params_default(crt_params*);
 int crt_set_counting(crt_ctx*, int on);   /* per-ray test counters for the algorithmic-bytes figure (slower) */
 
 /* ---- scene: replaces the app-side std::vector<SceneObject*> / std::vector<Light> (main.cu:230-321,
- *      464-488) that startRayTracing receives (Ray.cu:665) ---- */
+ *      464-488) that startRayTracing receives (Ray.cu:665).  Coordinates must be finite and sphere radii >= 0 (CRT_ERR_ARG
+ *      otherwise: with a negative radius the reference's boxes are inverted and what a ray then hits depends on the
+ *      composition of that one tree's leaves); every other value is taken as the reference takes it, NaN and infinity in
+ *      materials and lights included (crt_params.zero_paths) ---- */
 int crt_scene_set(crt_ctx*, const crt_prim* prims, int n);
 int crt_scene_update(crt_ctx*, const crt_prim* prims, int n);   /* moved geometry; same count and order */
 int crt_lights_set(crt_ctx*, const crt_light* lights, int n);

@@ -159,7 +159,7 @@ def hostile_scene(crt, rng):
     return prims, kind
 
 
-@pytest.mark.parametrize("seed", list(range(24)))
+@pytest.mark.parametrize("seed", list(range(40)))
 def test_scenes_that_shade_to_nan_equal_the_oracle(crt, seed):
     """NaN and infinity are reference behaviour too (Ray.cu:655-660 adds them like any colour; the 8-bit conversion of Ray.cu:724-731
     then decides the pixel): same frame, same rays."""
@@ -170,6 +170,10 @@ def test_scenes_that_shade_to_nan_equal_the_oracle(crt, seed):
         lights[0]["direction"] = 0; lights[0]["point"] = 0; lights[0]["area"] = 0          # normalize(0), Ray.cu:635
     if seed % 4 == 2 and len(lights):
         lights[-1]["color"] = (np.inf, 1e30, -np.inf)          # 0 * inf for the points it does not reach (Ray.cu:629,655)
+    if seed % 4 == 1 and len(lights):
+        for l in lights:          # attenuation 1 / 0 = inf -> .5 (Ray.cu:610-612), negative attenuation, a disk of radius 0 and of negative radius
+            if l["area"]: l["radius"] = rng.choice([0.0, -15.0])
+            elif l["point"]: l["constantTerm"], l["linearTerm"], l["quadraticTerm"] = ((0, 0, 0) if rng.integers(0, 2) else (-0.5, 0.001, 0))
     w, h, bounces = int(rng.integers(40, 120)), int(rng.integers(30, 90)), int(rng.integers(2, 5))
     cam = rng.uniform(-150, 150, 3).astype(np.float32)
     tgt = rng.uniform(-40, 40, 3).astype(np.float32)
@@ -499,3 +503,37 @@ def test_many_lights_many_samples_many_bounces(crt, seed):
         print(f"seed {seed} mode {mode}: {w}x{h} bounces={bounces} area_samples={area_samples} rays={rays} exact={int((diff == 0).sum())}/{w * h}")
         assert int((diff > 0).sum()) == 0
         assert rays == ost["live_traversals"]
+
+
+@pytest.mark.parametrize("case", ["camera at its target", "camera straight above its target", "camera below, looking up", "camera outside the room"])
+def test_degenerate_cameras(crt, case):
+    """Ray.cu:684-689 with a camera whose basis is NaN (n = normalize(0); cross((0,1,0), n) = 0): every primary ray is NaN, hits
+    neither object nor wall, and the path ends with the colour it has -- nothing.  And a camera outside the room."""
+    prims = crt.scene_teapot(with_sphere=True)
+    lights = crt.default_lights()
+    cam, tgt = {"camera at its target": ((10, 20, 30), (10, 20, 30)), "camera straight above its target": ((0, 150, 0), (0, 0, 0)),
+                "camera below, looking up": ((5, -150, 7), (5, 100, 7)), "camera outside the room": ((900, 400, 1200), (0, 0, 0))}[case]
+    cam, tgt = np.array(cam, np.float32), np.array(tgt, np.float32)
+    o, ost, frames = _frame_pair(crt, prims, lights, cam, tgt, 96, 54, 3)
+    for mode, g, rays in frames:
+        assert np.array_equal(g, o["bgr"]), f"{case}, mode {mode}"
+        assert rays == ost["live_traversals"], f"{case}, mode {mode}"
+
+
+def test_negative_radius_is_rejected(crt):
+    """the one input the reference accepts and this library does not: a sphere of negative radius.  intersectSphere squares the
+    radius (Ray.cu:110) but bvh.cu's boxes come out inverted, so whether a ray reaches the sphere depends on what shares its
+    64-primitive leaf in that one tree; crt_scene_set / crt_scene_update return CRT_ERR_ARG instead.  Radius 0 is accepted."""
+    prims = crt.scene_spheres(10, seed=1)
+    ctx = crt.Context(0)
+    try:
+        prims["radius"][3] = 0.0
+        ctx.set_scene(prims); ctx.build(0)
+        bad = prims.copy(); bad["radius"][4] = -2.0
+        with pytest.raises(crt.CrtError):
+            ctx.update_scene(bad)
+        with pytest.raises(crt.CrtError):
+            ctx.set_scene(bad)
+        ctx.render(*crt.default_camera(), crt.default_params(width=64, height=32, bounces=2))          # the scene set before is intact
+    finally:
+        ctx.close()
