@@ -809,6 +809,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                         key = ~0ull;
                         if (best >= 0) {
                             uint32_t tb = __float_as_uint(tbest);
+                            if (tb == 0x80000000u) tb = 0u;                        /* -0 == +0 for the '<' of Ray.cu:199,216: one key, the rank decides */
                             tb ^= (tb >> 31) ? 0xffffffffu : 0x80000000u;          /* unsigned order = float order */
                             key = ((unsigned long long)tb << 32) | (unsigned long long)A.sv.rank[best];
                         }
@@ -817,7 +818,8 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                     }
                     atomicMin(&s_key[oi], key);
                     __builtin_amdgcn_wave_barrier();
-                    if (!shray && best >= 0 && s_key[oi] == key) s_best[oi] = (uint32_t)best;
+                    /* bit 31: the winner's t is -0 (the key holds +0 for it; slots are < 2^24) */
+                    if (!shray && best >= 0 && s_key[oi] == key) s_best[oi] = (uint32_t)best | (__float_as_uint(tbest) == 0x80000000u ? 0x80000000u : 0u);
                     __builtin_amdgcn_wave_barrier();
                     if (atomicSub(&s_cnt[oi], 1u) == 1u) {
                         const unsigned long long kmin = s_key[oi];
@@ -826,8 +828,9 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                             else {
                                 uint32_t tb = (uint32_t)(kmin >> 32);
                                 tb ^= (tb >> 31) ? 0x80000000u : 0xffffffffu;
-                                A.hitSlot[ray] = (int32_t)s_best[oi];
-                                A.hitT[ray] = __uint_as_float(tb);
+                                const uint32_t sb = s_best[oi];
+                                A.hitSlot[ray] = (int32_t)(sb & 0x7fffffffu);
+                                A.hitT[ray] = __uint_as_float(tb | (sb & 0x80000000u));
                             }
                         } else if (kmin == 1ull) A.shflag[ray & 0x7fffffffu] = 1;
                     }

@@ -537,3 +537,127 @@ def test_negative_radius_is_rejected(crt):
         ctx.render(*crt.default_camera(), crt.default_params(width=64, height=32, bounces=2))          # the scene set before is intact
     finally:
         ctx.close()
+
+
+def lattice_scene(crt, rng):
+    """triangles with vertices on an integer lattice: axis-aligned and coplanar faces (boxes of zero thickness), shared edges
+    and vertices everywhere, plus spheres centred on lattice points with integer radii"""
+    ntri, nsph = int(rng.integers(50, 800)), int(rng.integers(0, 30))
+    tri = crt.scene_soup(ntri, seed=1)
+    base = rng.integers(-12, 13, (ntri, 3)) * 8
+    axis = rng.integers(0, 4, ntri)          # 0..2: a face in the plane normal to that axis; 3: any lattice triangle
+    for i in range(ntri):
+        if axis[i] < 3:
+            a, b = [k for k in range(3) if k != axis[i]]
+            e1 = np.zeros(3); e2 = np.zeros(3)
+            e1[a] = 8 * rng.integers(1, 4); e2[b] = 8 * rng.integers(1, 4)
+            if rng.integers(0, 2): e1[b] = e2[b]                      # the other half of the same lattice cell
+        else:
+            e1 = rng.integers(-2, 3, 3) * 8.0; e2 = rng.integers(-2, 3, 3) * 8.0
+        tri["v1"][i] = base[i]; tri["v2"][i] = base[i] + e1; tri["v3"][i] = base[i] + e2
+        g = np.cross(e1, e2)
+        ng = g / np.linalg.norm(g) if np.linalg.norm(g) > 0 else np.array([0.0, 1.0, 0.0])
+        tri["v1Norm"][i] = tri["v2Norm"][i] = tri["v3Norm"][i] = ng
+    sph = crt.scene_spheres(nsph, seed=2) if nsph else np.zeros(0, crt.PRIM_DTYPE)
+    if nsph:
+        sph["position"] = (rng.integers(-12, 13, (nsph, 3)) * 8).astype(np.float32)
+        sph["radius"] = rng.integers(1, 5, nsph).astype(np.float32) * 4
+    prims = np.concatenate([tri, sph])
+    prims["reflective"] = rng.uniform(0, 1, (len(prims), 3)).astype(np.float32)
+    prims = np.ascontiguousarray(prims[rng.permutation(len(prims))])
+    prims["objNum"] = np.arange(len(prims), dtype=np.int32)
+    return prims
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_lattice_scenes_rays_through_edges_and_vertices(crt, seed):
+    """cameras on lattice points with power-of-two frame sizes: many primary rays run exactly through shared edges and vertices
+    and along axis-aligned faces (grazing hits; zero direction components, boxes of zero thickness).  The traced
+    rays themselves are compared too, through the parity hook: 100 k rays between random lattice points."""
+    rng = np.random.default_rng(17000 + seed)
+    for _ in range(20):          # the reference's builder recurses forever on some of these (> 64 equal centroid coordinates, tests/test_host_layer.py)
+        prims = lattice_scene(crt, rng)
+        sc = orc.Scene(prims)
+        try:
+            sc.build()
+            break
+        except RuntimeError:
+            prims = None
+        finally:
+            sc.close()
+    assert prims is not None
+    lights = random_lights(crt, rng)
+    cam = (rng.integers(-14, 15, 3) * 8).astype(np.float32)
+    tgt = (rng.integers(-3, 4, 3) * 8).astype(np.float32)
+    if np.array_equal(cam, tgt) or (cam[0] == tgt[0] and cam[2] == tgt[2]):
+        cam = cam + np.float32(8) * np.array([1, 0, 1], np.float32)
+    w, h = int(rng.choice([64, 128])), int(rng.choice([32, 64]))
+    o, ost, frames = _frame_pair(crt, prims, lights, cam, tgt, w, h, 3)
+    for mode, g, rays in frames:
+        assert np.array_equal(g, o["bgr"]), f"seed {seed} mode {mode}: {int((g != o['bgr']).any(axis=2).sum())} pixels differ"
+    n = 100000
+    a = (rng.integers(-14, 15, (n, 3)) * 8).astype(np.float32)
+    b = (rng.integers(-14, 15, (n, 3)) * 8).astype(np.float32)
+    d = (b - a).astype(np.float64)
+    ln = np.linalg.norm(d, axis=1, keepdims=True)
+    keep = ln[:, 0] > 0
+    raysv = np.concatenate([a[keep], (d[keep] / ln[keep]).astype(np.float32)], axis=1)
+    sc = orc.Scene(prims); sc.build()
+    try:
+        ids_o, ts_o = sc.trace(raysv, nthreads=16)
+    finally:
+        sc.close()
+    for mode in (0, 2):
+        ctx = crt.Context(0)
+        try:
+            ctx.set_scene(prims); ctx.build(mode)
+            ids_g, ts_g = ctx.trace(raysv)
+        finally:
+            ctx.close()
+        bad = int((ids_g != ids_o).sum())
+        print(f"seed {seed} mode {mode}: lattice rays={len(raysv)} hits={int((ids_o >= 0).sum())} id mismatches={bad} t equal={bool(np.array_equal(ts_g, ts_o))}")
+        same = ids_g == ids_o
+        if bad:
+            # SURVEY 9.1 G3, the one class these scenes do produce: the reference's own slab test (Ray.cu:54-104) rejects a box of
+            # zero thickness for a ray that runs inside its plane (0 * inf), and with it a primitive its own loop over all
+            # primitives hits.  A mismatch is accepted only if it is exactly that: the HIP path reports the brute-force hit,
+            # the reference's tree does not.
+            from parity_classes import classify
+            idx = np.flatnonzero(~same)
+            sc = orc.Scene(prims); sc.build()
+            try:
+                ib, tb = sc.trace_brute(raysv[idx], nthreads=16)
+                g3 = (ib == ids_g[idx]) & (tb == ts_g[idx]) & ((ib != ids_o[idx]) | (tb != ts_o[idx]))
+                why = classify(ids_g, ts_g, ids_o, ts_o, ~same, sc, raysv, prims) if not g3.all() else ""
+            finally:
+                sc.close()
+            assert g3.all(), f"seed {seed} mode {mode}: {int((~g3).sum())} mismatches that are not box false-negatives of the reference: {why}"
+            assert bad <= 20
+        assert np.array_equal(ts_g[same].view(np.uint32), ts_o[same].view(np.uint32)), f"seed {seed} mode {mode}"
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_cameras_inside_spheres_and_arbitrary_vertex_normals(crt, seed):
+    """spheres that contain the camera and each other (negative roots, the smaller root of Ray.cu:135 kept for the hit point),
+    and triangles whose vertex normals have nothing to do with their plane or with unit length (the shading normal is
+    normalize of their mix, Ray.cu:168-172)"""
+    rng = np.random.default_rng(19000 + seed)
+    prims = random_scene(crt, rng)
+    n = len(prims)
+    for f in ("v1Norm", "v2Norm", "v3Norm"):
+        prims[f] = (rng.normal(size=(n, 3)) * rng.uniform(0.01, 30, (n, 1))).astype(np.float32)
+    cam = rng.uniform(-100, 100, 3).astype(np.float32)
+    tgt = rng.uniform(-40, 40, 3).astype(np.float32)
+    big = crt.scene_spheres(3, seed=5)
+    big["position"][0] = cam + rng.uniform(-20, 20, 3).astype(np.float32); big["radius"][0] = 90.0
+    big["position"][1] = cam + rng.uniform(-5, 5, 3).astype(np.float32); big["radius"][1] = 30.0
+    big["position"][2] = tgt; big["radius"][2] = 55.0
+    big["reflective"] = rng.uniform(0.3, 1, (3, 3)).astype(np.float32)
+    prims = np.concatenate([prims, big])
+    prims["objNum"] = np.arange(len(prims), dtype=np.int32)
+    lights = random_lights(crt, rng)
+    w, h, bounces = int(rng.integers(50, 150)), int(rng.integers(40, 100)), int(rng.integers(2, 5))
+    o, ost, frames = _frame_pair(crt, prims, lights, cam, tgt, w, h, bounces)
+    for mode, g, rays in frames:
+        assert np.array_equal(g, o["bgr"]), f"seed {seed} mode {mode}: {int((g != o['bgr']).any(axis=2).sum())} pixels differ"
+        assert rays == ost["traversals"]          # the arbitrary normals are not on one side of their triangles: zero-coefficient paths are traced on
