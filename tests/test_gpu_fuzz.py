@@ -666,3 +666,33 @@ def test_cameras_inside_spheres_and_arbitrary_vertex_normals(crt, seed):
     for mode, g, rays in frames:
         assert np.array_equal(g, o["bgr"]), f"seed {seed} mode {mode}: {int((g != o['bgr']).any(axis=2).sum())} pixels differ"
         assert rays == ost["traversals"]          # the arbitrary normals are not on one side of their triangles: zero-coefficient paths are traced on
+
+
+@pytest.mark.parametrize("seed", list(range(4)))
+def test_random_scenes_at_frame_sizes_that_fill_the_chip(crt, seed):
+    """the families above on 960 x 540 frames (0.5 M primary rays: the traversal's main loop with its queue refills, not only
+    the tail that small frames live in): a random scene, a hostile one, a lattice one per seed"""
+    rng = np.random.default_rng(23000 + seed)
+    w, h, bounces = 960, 540, 3
+    scenes = [("random", random_scene(crt, rng)), ("hostile", hostile_scene(crt, rng)[0])]
+    for _ in range(20):
+        p = lattice_scene(crt, rng)
+        sc = orc.Scene(p)
+        try:
+            sc.build(); scenes.append(("lattice", p)); break
+        except RuntimeError:
+            pass
+        finally:
+            sc.close()
+    for name, prims in scenes:
+        lights = random_lights(crt, rng)
+        cam = (rng.integers(-14, 15, 3) * 8).astype(np.float32) if name == "lattice" else rng.uniform(-150, 150, 3).astype(np.float32)
+        tgt = rng.uniform(-40, 40, 3).astype(np.float32)
+        if cam[0] == tgt[0] and cam[2] == tgt[2]:
+            cam[0] += 8
+        o, ost, frames = _frame_pair(crt, prims, lights, cam, tgt, w, h, bounces, modes=(0, 2), area_samples=4)
+        for mode, g, rays in frames:
+            nbad = int((g != o["bgr"]).any(axis=2).sum())
+            print(f"seed {seed} {name} mode {mode}: {len(prims)} prims, {len(lights)} lights, rays={rays} oracle={ost['traversals']} live={ost['live_traversals']} differing pixels={nbad}")
+            assert nbad == 0, f"seed {seed} {name} mode {mode}"
+            assert rays in (ost["traversals"], ost["live_traversals"])
