@@ -696,3 +696,63 @@ def test_random_scenes_at_frame_sizes_that_fill_the_chip(crt, seed):
             print(f"seed {seed} {name} mode {mode}: {len(prims)} prims, {len(lights)} lights, rays={rays} oracle={ost['traversals']} live={ost['live_traversals']} differing pixels={nbad}")
             assert nbad == 0, f"seed {seed} {name} mode {mode}"
             assert rays in (ost["traversals"], ost["live_traversals"])
+
+
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_graph_replay_under_random_changes(crt, seed):
+    """crt_params.use_graph = 1 next to a twin context that launches plainly, through 30 random changes of everything a captured
+    graph could have baked in: camera, frame size, bounces, spp, lights (also to ones that can shade to NaN: zero_paths flips),
+    scene contents (animation, refit, host update), the tree (rebuilds on either builder), a wholly different scene, capture
+    and counting switches, zero_paths itself.  Every frame must equal the twin's."""
+    rng = np.random.default_rng(29000 + seed)
+    a = crt.Context(0); b = crt.Context(0)
+
+    def new_scene():
+        p = random_scene(crt, rng)
+        p["direction"] = rng.normal(size=(len(p), 3)).astype(np.float32)
+        p["speed"] = rng.uniform(0, 1, len(p)).astype(np.float32)
+        return p
+    try:
+        prims = new_scene()
+        lights = random_lights(crt, rng)
+        for c in (a, b):
+            c.set_scene(prims); c.set_lights(lights); c.build(0)
+        cam = rng.uniform(-150, 150, 3).astype(np.float32); tgt = rng.uniform(-40, 40, 3).astype(np.float32)
+        kw = dict(width=96, height=64, bounces=2, spp=1, zero_paths=0, area_samples=3)
+        log = []
+        for step in range(30):
+            what = int(rng.integers(0, 12))
+            log.append(what)
+            if what == 0: cam = rng.uniform(-150, 150, 3).astype(np.float32)
+            elif what == 1: kw["width"], kw["height"] = int(rng.integers(20, 200)), int(rng.integers(20, 120))
+            elif what == 2: kw["bounces"] = int(rng.integers(1, 5))
+            elif what == 3: kw["spp"] = int(rng.choice([1, 4]))
+            elif what == 4:
+                lights = random_lights(crt, rng)
+                if len(lights) and rng.integers(0, 3) == 0: lights[0]["color"] = (np.inf, 0, 0)
+                for c in (a, b): c.set_lights(lights)
+            elif what == 5:
+                for c in (a, b): c.animate_device(); c.refit(bool(rng.integers(0, 2)))
+            elif what == 6:
+                m = int(rng.choice([0, 2]))
+                for c in (a, b): c.build(m)
+            elif what == 7:
+                prims = new_scene()
+                m = int(rng.choice([0, 2]))
+                for c in (a, b): c.set_scene(prims); c.build(m)
+            elif what == 8:
+                on = bool(rng.integers(0, 2))
+                for c in (a, b): c.set_capture(on)
+            elif what == 9: kw["zero_paths"] = int(rng.integers(0, 3))
+            elif what == 10:
+                host = a.get_scene()
+                crt.animate_host(host)
+                for c in (a, b): c.update_scene(host); c.refit(False)
+            # what == 11: nothing changes -- a pure replay
+            want = a.render(cam, tgt, crt.default_params(**kw)).copy()
+            got = b.render(cam, tgt, crt.default_params(use_graph=1, **kw))
+            assert np.array_equal(want, got), f"seed {seed} step {step}: changes so far {log}"
+            sa, sb = a.stats(), b.stats()
+            assert (sa["rays_primary"], sa["rays_shadow"], sa["rays_reflect"]) == (sb["rays_primary"], sb["rays_shadow"], sb["rays_reflect"])
+    finally:
+        a.close(); b.close()
