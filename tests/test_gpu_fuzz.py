@@ -6,6 +6,8 @@ happens to contain: spheres and triangles sharing leaves, materials from black t
 lights inside the geometry, cameras inside the room looking anywhere, frames that are not multiples of the tile.
 Bar as in test_gpu_parity.py: every pixel within 1 LSB (in practice equal), per-bounce hit ids equal.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -287,7 +289,7 @@ def test_random_animation_loop_on_frame_slots_equals_the_oracle(crt, seed):
     try:
         ctx.set_scene(prims); ctx.set_lights(lights); ctx.build(int(rng.choice([0, 2])))
         building = False
-        for step in range(14):
+        for step in range(int(os.environ.get("CRT_FUZZ_STEPS", "14"))):          # a soak: CRT_FUZZ_STEPS=400
             # ---- move the scene
             on_device = bool(rng.integers(0, 2)) and not building       # crt_scene_update during an asynchronous build is fine too, but keep the host copy in step
             crt.animate_host(host); sc.animate()
