@@ -94,9 +94,14 @@ def test_reference_topology_equals_oracle_tree(crt, scene):
              "soup": lambda: crt.scene_soup(20000, seed=5), "small": lambda: crt.scene_spheres(40, seed=1),
              # large enough for the builders to hand subtrees to other threads (ranges above max(n/64, 8192) primitives)
              "soup_threaded": lambda: crt.scene_soup(120000, seed=6)}[scene]()
+    compare_with_oracle_tree(crt, prims)
+
+
+def compare_with_oracle_tree(crt, prims):
     sc = orc.Scene(prims)
     sc.build()
     d = sc.dump()
+    sc.close()
     h = crt.host_bvh(prims, 1)
     order = np.concatenate([l for l in walk_oracle(d)]) if len(prims) else np.zeros(0, np.int32)
     assert np.array_equal(h["slot_to_scene"], order.astype(np.uint32))
@@ -122,6 +127,35 @@ def test_reference_topology_equals_oracle_tree(crt, scene):
         rec(0, boxes[0, 0], int(links[0, 0]))
     else:
         rec(0, h["root"], 0)
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_scenes_build_the_oracle_s_tree(crt, seed):
+    """the generators of tests/test_gpu_fuzz.py (triangles and spheres interleaved, stretched, on a lattice with many equal
+    centroid coordinates and boxes of zero thickness): newBuild/constructTree restated in the product gives the oracle's tree,
+    leaf for leaf and box for box; where the reference recurses forever both sides say so; the wide tree is a valid hierarchy
+    with exact leaf boxes either way"""
+    from test_gpu_fuzz import lattice_scene, random_scene
+    rng = np.random.default_rng(31000 + seed)
+    prims = lattice_scene(crt, rng) if seed % 3 == 2 else random_scene(crt, rng)
+    if seed % 4 == 1:          # everything below the origin: the reference's maxima start at 0 (main.cu:35, tests/test_gpu_robustness.py)
+        for f in ("position", "v1", "v2", "v3"):
+            prims[f] = prims[f] - np.float32(400)
+    check_wide_hierarchy(crt, prims)
+    sc = orc.Scene(prims)
+    try:
+        try:
+            sc.build()
+            builds = True
+        except RuntimeError:
+            builds = False
+    finally:
+        sc.close()
+    if builds:
+        compare_with_oracle_tree(crt, prims)
+    else:
+        with pytest.raises(crt.CrtError):
+            crt.host_bvh(prims, 1)
 
 
 def check_wide_hierarchy(crt, prims):
