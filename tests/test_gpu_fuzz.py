@@ -758,3 +758,50 @@ def test_graph_replay_under_random_changes(crt, seed):
             assert (sa["rays_primary"], sa["rays_shadow"], sa["rays_reflect"]) == (sb["rays_primary"], sb["rays_shadow"], sb["rays_reflect"])
     finally:
         a.close(); b.close()
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_device_build_replays_the_reference_order_on_random_scenes(crt, seed):
+    """refrank.hip against the host restatement of newBuild/constructTree (itself equal to the oracle's tree on these
+    generators, tests/test_host_layer.py): the same rank for every primitive on random, lattice (many equal centroid
+    coordinates: splits that separate nothing, ties in the mean) and below-origin scenes (the reference's box maxima start at 0,
+    main.cu:35); where the reference's recursion never ends, neither side has an order"""
+    rng = np.random.default_rng(31000 + seed)
+    prims = lattice_scene(crt, rng) if seed % 3 == 2 else random_scene(crt, rng)
+    if seed % 4 == 1:
+        for f in ("position", "v1", "v2", "v3"):
+            prims[f] = prims[f] - np.float32(400)
+    ctx = crt.Context(0)
+    try:
+        ctx.set_scene(prims)
+        ctx.build(0)
+        try:
+            host = ctx.reference_order().copy()
+        except crt.CrtError:
+            host = None
+        ctx.build(2)
+        if host is None:
+            with pytest.raises(crt.CrtError):
+                ctx.reference_order()
+        else:
+            dev = ctx.reference_order()
+            assert np.array_equal(dev, host), f"seed {seed}: {int((dev != host).sum())} of {len(prims)} ranks differ"
+        # and once more after the scene has moved: the asynchronous builder's snapshot path
+        ctx.animate_device(); ctx.build_async(); assert ctx.swap(wait=True)
+        moved = ctx.get_scene()
+        twin = crt.Context(0)
+        try:
+            twin.set_scene(moved); twin.build(0)
+            try:
+                want = twin.reference_order().copy()
+            except crt.CrtError:
+                want = None
+        finally:
+            twin.close()
+        if want is None:
+            with pytest.raises(crt.CrtError):
+                ctx.reference_order()
+        else:
+            assert np.array_equal(ctx.reference_order(), want), f"seed {seed}: after the asynchronous rebuild"
+    finally:
+        ctx.close()
