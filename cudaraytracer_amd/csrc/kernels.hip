@@ -519,6 +519,32 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
      * and the idle lanes share the work of the busy ones (the steal step).  Keeping the two apart keeps the sharing logic
      * (shared write-out, empty stack entries, 20 lane shuffles) out of the loop where 97 % of the time goes: in one loop
      * it cost 19 % of the frame.  Returns true when the loop should end. */
+    /* result of a finished ray whose lanes did not share it: nearest hit, or the shadow predicate */
+    auto write_result = [&]() __attribute__((always_inline)) {
+        if (!(ray >> 31)) {
+            A.hitSlot[ray] = best;
+            A.hitT[ray] = tbest;
+        } else {
+            bool shadowed;
+            if (lkind != kShadowDirectional && !(fstate & 1u)) {
+                shadowed = false;
+                if (best >= 0) {
+                    /* Ray.cu:625-629; k_shade computed dtoLight from this very origin */
+                    const vec3 ipoint = o + tbest * d;
+                    const float dtoLight = __uint_as_float(lkind & 0x7fffffffu);
+                    const float fx = ipoint.x - o.x, fy = ipoint.y - o.y, fz = ipoint.z - o.z;
+                    const float dtoLightIntersection = sqrtf(fx * fx + fy * fy + fz * fz);
+                    shadowed = dtoLight > dtoLightIntersection;
+                    if ((lkind >> 31) && !(tbest > 0.000000001f)) shadowed = false;   /* area samples: Ray.cu:589 */
+                }
+            } else shadowed = ((fstate & 1u) != 0);
+            if (shadowed) A.shflag[ray & 0x7fffffffu] = 1;
+        }
+    };
+    /* fstate bit 25: the lane's ray has finished in the main loop and its result is still in the lane's registers.  Writing it out
+     * in the finishing iteration ran the write-out for one or two lanes in a third of all iterations; a finished lane idles until
+     * the next refill anyway, so the result is written when the lane is set up for its next ray (or when the queue runs dry) */
+    constexpr uint32_t kZombie = 1u << 25;
 #define CRT_MARK8(NAME) if constexpr (!TAIL) { CRT_MARK(NAME) }
     auto iteration = [&](auto tail_tag) __attribute__((always_inline)) -> bool {
         constexpr bool TAIL = decltype(tail_tag)::value;
@@ -526,8 +552,8 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
         /* ---- refill, first half: when enough lanes are idle, take rays off the queue and ISSUE their
          *      loads; the set-up runs after this iteration's traversal step, whose own node / primitive
          *      loads return later (loads return in order), so the refill costs the wave no extra stall ---- */
-        bool pend = false;
-        float4 pro4, prd;      /* read only by the lanes that set pend; `ray` carries the queue index */
+        bool pend = false, pend_sh = false;
+        float4 pro4, prd;      /* read only by the lanes that set pend; a ray record carries its own index / result slot in .w of its origin */
         /* one vote on `active` serves the refill trigger, the "anything to do" test and the node count below: every
          * vote on a bool costs two VALU instructions (the compiler rebuilds the lane mask through a VGPR) */
         const unsigned long long amask = crt_ballot(active);
@@ -623,15 +649,16 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                     const uint32_t idx = cnext + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                     const uint32_t take = (uint32_t)nidle < cend - cnext ? (uint32_t)nidle : cend - cnext;
                     const bool sh = cnext < ns64;          /* wave-uniform: the chunk lies in one queue */
+                    pend_sh = sh;
                     const bool mine = !active && idx < cend && (!sh || idx < total_s);
                     cnext += take;
                     if (mine) {          /* issue the loads only: they complete under the traversal step below */
                         if (sh) {
                             const uint32_t q = A.shperm ? A.shperm[idx] : idx;      /* sorted visiting order, if any */
-                            pro4 = A.shO[q]; prd = A.shD[q]; ray = q | 0x80000000u;
+                            pro4 = A.shO[q]; prd = A.shD[q];
                         } else {
                             const uint32_t q = A.perm ? A.perm[idx - ns64] : idx - ns64;
-                            pro4 = A.rayO[q]; prd = A.rayD[q]; ray = q;
+                            pro4 = A.rayO[q]; prd = A.rayD[q];
                         }
                         pend = true;
                     }
@@ -834,26 +861,8 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                             }
                         } else if (kmin == 1ull) A.shflag[ray & 0x7fffffffu] = 1;
                     }
-                } else
-                if (!(ray >> 31)) {
-                    A.hitSlot[ray] = best;
-                    A.hitT[ray] = tbest;
-                } else {
-                    bool shadowed;
-                    if (lkind != kShadowDirectional && !(fstate & 1u)) {
-                        shadowed = false;
-                        if (best >= 0) {
-                            /* Ray.cu:625-629; k_shade computed dtoLight from this very origin */
-                            const vec3 ipoint = o + tbest * d;
-                            const float dtoLight = __uint_as_float(lkind & 0x7fffffffu);
-                            const float fx = ipoint.x - o.x, fy = ipoint.y - o.y, fz = ipoint.z - o.z;
-                            const float dtoLightIntersection = sqrtf(fx * fx + fy * fy + fz * fz);
-                            shadowed = dtoLight > dtoLightIntersection;
-                            if ((lkind >> 31) && !(tbest > 0.000000001f)) shadowed = false;   /* area samples: Ray.cu:589 */
-                        }
-                    } else shadowed = ((fstate & 1u) != 0);
-                    if (shadowed) A.shflag[ray & 0x7fffffffu] = 1;
-                }
+                } else if constexpr (TAIL) write_result();
+                else fstate |= kZombie;          /* main loop: the result is written when the lane takes its next ray (refill2) */
                 active = false; lp = lend = 0; plm = 0;
             }
             CRT_MARK8("finish_end")
@@ -863,16 +872,18 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
         /* ---- refill, second half: ray set-up for the lanes whose loads were issued above ---- */
         if constexpr (!TAIL)
         if (pend) {
+            if (fstate & kZombie) write_result();
             const float4 ro = pro4, rd = prd;
-            const bool shray = (ray >> 31) != 0u;
-            const uint32_t idx = ray & 0x7fffffffu;
+            const bool shray = pend_sh;
+            const uint32_t idx = __float_as_uint(ro.w);      /* nearest-hit ray: its own queue index; shadow ray: the flag it may set */
             if (!shray && __float_as_uint(rd.w) == 0xffffffffu) {
                 A.hitSlot[idx] = -3;
                 A.hitT[idx] = 0.f;
+                fstate &= ~kZombie;
             } else {
                 ray = idx;
                 o = vec3(ro.x, ro.y, ro.z); d = vec3(rd.x, rd.y, rd.z);
-                if (shray) { ray = __float_as_uint(ro.w) | 0x80000000u; lkind = __float_as_uint(rd.w); }
+                if (shray) { ray = idx | 0x80000000u; lkind = __float_as_uint(rd.w); }
                 /* v_rcp_f32 (1 ulp) instead of an IEEE division: the box test only has to be
                  * conservative and the pad below is 1e4 times that error */
                 float rx = __builtin_amdgcn_rcpf(d.x), ry = __builtin_amdgcn_rcpf(d.y), rz = __builtin_amdgcn_rcpf(d.z);
@@ -900,6 +911,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
         else return exhausted;
     };
     while (!iteration(std::false_type{})) {}
+    if (fstate & kZombie) { write_result(); fstate &= ~kZombie; }      /* the queue is dry: nothing will be set up on this lane again */
     unsigned long long t_dry = 0;
     if (A.tail_probe) t_dry = __builtin_readcyclecounter();      /* s_memtime; CRT_TAIL_PROBE=1 only */
     CRT_MARK("tail_begin")
@@ -1206,14 +1218,14 @@ __global__ __launch_bounds__(256) void k_gen_primary(FrameParams P, FrameBuffers
         const int px = (int)((tile % (uint32_t)P.tiles_x) * (uint32_t)P.tile_w + (blk % bpr) * 8u + (l & 7u));
         const int py = (int)((tile / (uint32_t)P.tiles_x) * (uint32_t)P.tile_h + (blk / bpr) * 8u + (l >> 3));
         if (!(px < P.width && py < P.height)) {
-            B.rayO[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            B.rayO[q] = make_float4(0.f, 0.f, 0.f, __uint_as_float(q));
             B.rayD[q] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffffffu));
             B.pix[q] = 0xffffffffu;
             continue;
         }
         const vec3 cam(P.cam);
         const vec3 sample = primary_direction(P, px, py);
-        B.rayO[q] = make_float4(cam.x, cam.y, cam.z, 0.f);
+        B.rayO[q] = make_float4(cam.x, cam.y, cam.z, __uint_as_float(q));      /* .w: the ray's own queue index (k_trace8 takes it from here) */
         B.rayD[q] = make_float4(sample.x, sample.y, sample.z, 0.f);
         B.pix[q] = (uint32_t)(py * P.width + px);
     }
@@ -1583,7 +1595,7 @@ __global__ CRT_SHADE_BOUNDS void k_shade(FrameParams P, FrameBuffers B, SceneVie
         if (emit) {
             const uint32_t kn = rf_base + (uint32_t)__popcll(emit_mask & ((1ull << lane) - 1ull));
             const vec3 rdir = normalize(reflect(d, N));
-            B.nrayO[kn] = make_float4(P_.x, P_.y, P_.z, 0.f);
+            B.nrayO[kn] = make_float4(P_.x, P_.y, P_.z, __uint_as_float(kn));
             B.nrayD[kn] = make_float4(rdir.x, rdir.y, rdir.z, 0.f);
             B.ncoef[kn] = make_float4(newcoef.x, newcoef.y, newcoef.z, 0.f);
             B.npix[kn] = pix;
