@@ -36,7 +36,7 @@ constexpr int kFetchDoneWord = 32;     /* word of the same zeroed block (its own
 constexpr int kTraceBlock = 256;       /* 4 waves of 64 */
 constexpr int kStackDepth = CRT_STACK_DEPTH;        /* per-lane entries in LDS: stack[depth][lane], conflict-free per wave */
 #ifndef CRT_REFILL8_MIN_IDLE
-#define CRT_REFILL8_MIN_IDLE 8         /* k_trace8: idle lanes that trigger a refill (its loads complete under the next traversal step) */
+#define CRT_REFILL8_MIN_IDLE 12         /* k_trace8: idle lanes that trigger a refill (its loads complete under the next traversal step) */
 #endif
 #ifndef CRT_TRACE8_MIN_WAVES
 #define CRT_TRACE8_MIN_WAVES 5         /* __launch_bounds__(256, n): 96 VGPRs, 5 waves per SIMD; 5 x 30.7 KB of LDS per CU */
