@@ -455,7 +455,10 @@ CRT_DEV void slab8(uint32_t& raw, uint32_t wnx, uint32_t wfx, uint32_t wny, uint
  * profiles/r03_rank_slice_async.jsonl): the whole 4K frame 17.05 / 17.81 / 17.98 ms for 256 / 128 / 64, and with three frames of
  * an eighth of it in flight 2.37 / 2.45 / 2.46 ms -- the same 0.90-0.91 of each variant's own ideal: what overlaps is not
  * block retirement, so the fastest single launch wins */
-template <bool COUNT, int BLOCK>
+/* OVF = false: the tree is no deeper than the in-LDS stack (TraceArgs::ovf_depth == 0, which the host derives from the blob
+ * header's depth: one stack entry per level at most), so neither pop nor push looks at the overflow rows in HBM -- two compares
+ * and two branches less per node step, and no spilled row pointer */
+template <bool COUNT, int BLOCK, bool OVF>
 __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
     constexpr int kDepth = stack_depth8_of(BLOCK);
     __shared__ uint2 s_stack[kDepth][BLOCK];
@@ -484,7 +487,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
     const uint32_t ns64 = (total_s + (uint32_t)kFetchChunk - 1u) / (uint32_t)kFetchChunk * (uint32_t)kFetchChunk;
     const uint32_t total = ns64 + total_n;
     const uint32_t gthread = blockIdx.x * BLOCK + tid;
-    uint2* ovf = reinterpret_cast<uint2*>(A.ovf) + (size_t)gthread * (size_t)(A.ovf_depth > 0 ? A.ovf_depth : 0);
+    uint2* ovf = OVF ? reinterpret_cast<uint2*>(A.ovf) + (size_t)gthread * (size_t)(A.ovf_depth > 0 ? A.ovf_depth : 0) : nullptr;
     const char* qbase = reinterpret_cast<const char*>(A.sv.qnodes);
 
     bool active = false;
@@ -689,7 +692,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                         else {
                             sp--;
                             uint2 e;
-                            if (sp < kDepth) e = s_stack[sp][tid];
+                            if (!OVF || sp < kDepth) e = s_stack[sp][tid];
                             else if (sp - kDepth < A.ovf_depth) e = ovf[sp - kDepth];
                             else { e = make_uint2(0u, 0u); finish = true; }
                             gbase = e.x; gmask = e.y;
@@ -702,7 +705,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                         gmask ^= 1u << pbit;
                         const uint32_t node = gbase + (uint32_t)__popc((gmask >> 8) & ((1u << slot) - 1u));
                         if (gmask & 0xffu) {
-                            if (sp < kDepth) s_stack[sp][tid] = make_uint2(gbase, gmask);
+                            if (!OVF || sp < kDepth) s_stack[sp][tid] = make_uint2(gbase, gmask);
                             else if (sp - kDepth < A.ovf_depth) ovf[sp - kDepth] = make_uint2(gbase, gmask);
                             else atomicOr(A.status, 1u);
                             sp++;
@@ -947,7 +950,7 @@ int trace_grid_blocks(int device) {
     /* persistent grid = what is resident at once: limited by the LDS stack per block and by the
      * kernel's VGPR allocation; ask the runtime for the tighter of the two */
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace8<false, 256>, 256, 0) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace8<false, 256, true>, 256, 0) != hipSuccess || per_cu < 1)
         per_cu = 4;
     if (per_cu > 8) per_cu = 8;
     return p.multiProcessorCount * per_cu;
@@ -965,8 +968,9 @@ bool trace8_has_block(int block) {
 template <int BLOCK>
 static void launch_trace8(const TraceArgs& a, bool counting, int blocks256, hipStream_t s) {
     dim3 g((unsigned)(blocks256 * (256 / BLOCK))), b(BLOCK);      /* the same number of waves whatever the block size */
-    if (counting) hipLaunchKernelGGL((k_trace8<true, BLOCK>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((k_trace8<false, BLOCK>), g, b, 0, s, a);
+    if (counting) hipLaunchKernelGGL((k_trace8<true, BLOCK, true>), g, b, 0, s, a);
+    else if (a.ovf_depth > 0 || BLOCK != 256) hipLaunchKernelGGL((k_trace8<false, BLOCK, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_trace8<false, BLOCK, BLOCK != 256>), g, b, 0, s, a);      /* 256 threads, shallow tree: no overflow code */
 }
 
 void launch_trace(const TraceArgs& a_in, int mode, bool counting, bool wide, int blocks, hipStream_t s) {

@@ -22,7 +22,7 @@ import os
 import re
 import sys
 
-KERNEL = os.environ.get("CRT_ISA_KERNEL", "_ZN3crt8k_trace8ILb0ELi256EEEvNS_9TraceArgsE")
+KERNEL = os.environ.get("CRT_ISA_KERNEL", "_ZN3crt8k_trace8ILb0ELi256ELb0EEEvNS_9TraceArgsE")
 # opcodes the microbenchmark does not cover are priced by a measured sibling of the same encoding / unit
 SIBLING = {
     "v_cndmask_b32_e64": "v_cndmask_b32 SGPR-pair mask (VOP3)",
@@ -120,7 +120,7 @@ def main():
             r["lds"] += 1
     for r in regions.values():
         r["valu_issue_cycles"] = round(r["valu_issue_cycles"], 2)
-    res = {"kernel": "k_trace8<false, 256>", "kernel_hash": digest.hexdigest()[:16], "waves_per_simd": k, "cost_source": ub,
+    res = {"kernel": "k_trace8<false, 256, false>", "kernel_hash": digest.hexdigest()[:16], "waves_per_simd": k, "cost_source": ub,
            "cycles_full_rate": cost["v_mov_b32"], "cycles_half_rate": half_default, "cycles_quarter_rate": cost["v_rcp_f32"],
            "regions": regions, "opcodes_priced_as_half_rate_by_default": unknown}
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
