@@ -700,7 +700,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                     }
                     CRT_MARK8("pop_end")
                     if (!finish && (!TAIL || (gmask & 0xffu) != 0u)) {          /* tail: a popped entry is empty when its group was given to another lane */
-                        const uint32_t pbit = 31u - (uint32_t)__clz((int)(gmask & 0xffu));
+                        const uint32_t pbit = 31u - (uint32_t)__builtin_clz(gmask & 0xffu);      /* not zero here: no guard for clz(0) */
                         const uint32_t slot = pbit ^ R;
                         gmask ^= 1u << pbit;
                         const uint32_t node = gbase + (uint32_t)__popc((gmask >> 8) & ((1u << slot) - 1u));
@@ -771,7 +771,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                     if (COUNT) { const bool any_ = crt_ballot(lp == lend) != 0ull; if (lane == 0 && any_) itc[5]++; }
                     CRT_MARK8("decode_begin")
                     if (lp == lend) {
-                        const uint32_t k = (uint32_t)__ffs((int)(plm >> 24)) - 1u;
+                        const uint32_t k = (uint32_t)__builtin_ctz(plm >> 24);      /* not zero: want_prim with lp == lend means a leaf hit is pending */
                         plm &= ~(1u << (24u + k));
                         const uint32_t m = ((k & 4u) ? meta1 : meta0) >> ((k & 3u) * 8u);
                         lp = (plm & 0xffffffu) + (m & 31u);
