@@ -63,7 +63,7 @@ constexpr int stack_depth8_of(int block) { return block >= 256 ? kStackDepth8 : 
 #define CRT_VOTE8_PRIM_WEIGHT 1
 #endif
 #ifndef CRT_VOTE8_NODE_WEIGHT
-#define CRT_VOTE8_NODE_WEIGHT 2
+#define CRT_VOTE8_NODE_WEIGHT 3
 #endif
 constexpr int kRefillMinIdle = CRT_REFILL_MIN_IDLE; /* a wave refills from the ray queue when >= this many lanes are idle */
 
