@@ -185,7 +185,7 @@ SceneView view_of(const crt_ctx* c) {
     v.rank = (const uint32_t*)(b + c->hdr.off_rank);
     v.sidx = (const uint32_t*)(b + c->hdr.off_sidx);
     v.mats = (const Material*)(b + c->hdr.off_mats);
-    v.nprims = c->hdr.nprims; v.nnodes = c->hdr.nnodes;
+    v.nprims = c->hdr.nprims; v.nnodes = c->hdr.nnodes; v.nmats = c->hdr.nmats;
     return v;
 }
 

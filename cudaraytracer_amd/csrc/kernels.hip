@@ -1377,6 +1377,7 @@ CRT_DEV float powf_libm(float x, float y, const double (*ltab)[2] = d_powlog2_ta
     return (float)w;
 }
 
+constexpr int kShadeMatsLds = 64;
 #ifndef CRT_SHADE_MIN_WAVES
 #define CRT_SHADE_MIN_WAVES 4          /* a floor only: with powf_libm instead of the device's double pow the kernel needs 93 VGPRs, no scratch (128 + 28 B before), i.e. 5 waves per SIMD; forcing 6 (79 VGPRs, 44 B of spill) gains 2 %, 8 loses 60 % */
 #endif
@@ -1393,6 +1394,14 @@ __global__ CRT_SHADE_BOUNDS void k_shade(FrameParams P, FrameBuffers B, SceneVie
     __shared__ uint32_t s_base[2];
     __shared__ double s_ltab[16][2];
     __shared__ unsigned long long s_etab[32];
+    /* the first kShadeMatsLds materials, in LDS: the material is the third of three dependent gathers per path (hit slot -> shading
+     * record -> material), and scenes have few materials */
+    __shared__ float4 s_mat[kShadeMatsLds][4];
+    static_assert(sizeof(Material) == 64, "four float4 per material");
+    {
+        const uint32_t nm4 = (sv.nmats < (uint32_t)kShadeMatsLds ? sv.nmats : (uint32_t)kShadeMatsLds) * 4u;
+        for (uint32_t t = threadIdx.x; t < nm4; t += blockDim.x) s_mat[t >> 2][t & 3u] = reinterpret_cast<const float4*>(sv.mats)[t];
+    }
     if (threadIdx.x < 32) { reinterpret_cast<double*>(s_ltab)[threadIdx.x] = reinterpret_cast<const double*>(d_powlog2_tab)[threadIdx.x]; s_etab[threadIdx.x] = d_exp2f_tab[threadIdx.x]; }
     __syncthreads();
     const uint32_t total = *count;
@@ -1446,7 +1455,14 @@ __global__ CRT_SHADE_BOUNDS void k_shade(FrameParams P, FrameBuffers B, SceneVie
                     const vec3 n1(s0.x, s0.y, s0.z), n2(s0.w, s1.x, s1.y), n3(s1.z, s1.w, s2.x);
                     N = normalize(uu * n1 + vv * n2 + ww * n3);
                 }
-                const Material m = sv.mats[__float_as_uint(s2.y)];
+                const uint32_t mi = __float_as_uint(s2.y);
+                Material m;
+                if (mi < (uint32_t)kShadeMatsLds) {
+                    const float4 m0 = s_mat[mi][0], m1 = s_mat[mi][1], m2 = s_mat[mi][2], m3 = s_mat[mi][3];
+                    m.ambient[0] = m0.x; m.ambient[1] = m0.y; m.ambient[2] = m0.z; m.diffuse[0] = m0.w; m.diffuse[1] = m1.x; m.diffuse[2] = m1.y;
+                    m.specular[0] = m1.z; m.specular[1] = m1.w; m.specular[2] = m2.x; m.reflective[0] = m2.y; m.reflective[1] = m2.z; m.reflective[2] = m2.w;
+                    m.shininess = m3.x;
+                } else m = sv.mats[mi];
                 const vec3 refl(m.reflective), amb(m.ambient);
                 if (raytype == 0) {
                     newcoef = refl; rc = vec3(1.0f, 1.0f, 1.0f);

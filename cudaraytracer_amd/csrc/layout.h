@@ -123,6 +123,7 @@ struct SceneView {
     const uint32_t* sidx;
     const Material* mats;
     uint32_t nprims, nnodes;
+    uint32_t nmats;
 };
 
 }  // namespace crt
