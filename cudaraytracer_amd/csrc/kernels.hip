@@ -1378,19 +1378,27 @@ CRT_DEV float powf_libm(float x, float y, const double (*ltab)[2] = d_powlog2_ta
 }
 
 constexpr int kShadeMatsLds = 64;
+/* Threads per block of k_shade.  Every block iteration reserves its queue space with ONE returning atomic per queue, and those
+ * atomics are what the kernel waits for: all resident blocks queue on the same two words, a round trip is (blocks in the queue) x
+ * ~12 ns, so the launch lasts (block iterations) x ~12 ns whatever else it does.  128 / 256 / 384 / 512 / 640 / 768 / 1024 threads:
+ * 2.51 / 1.49 / 1.50 / 1.32 / 1.57 / 1.34 / 1.58 ms of k_shade + k_resolve per 4K frame (6 waves per SIMD = 24 per CU: 512 and 768 fill them) */
+#ifndef CRT_SHADE_BLOCK
+#define CRT_SHADE_BLOCK 512
+#endif
+constexpr int kShadeBlock = CRT_SHADE_BLOCK;
 #ifndef CRT_SHADE_MIN_WAVES
-#define CRT_SHADE_MIN_WAVES 4          /* a floor only: with powf_libm instead of the device's double pow the kernel needs 93 VGPRs, no scratch (128 + 28 B before), i.e. 5 waves per SIMD; forcing 6 (79 VGPRs, 44 B of spill) gains 2 %, 8 loses 60 % */
+#define CRT_SHADE_MIN_WAVES 0          /* no floor: 74 VGPRs (materials from LDS, no SLP vectorizer), 6 waves per SIMD, no scratch */
 #endif
 #if CRT_SHADE_MIN_WAVES > 0
-#define CRT_SHADE_BOUNDS __launch_bounds__(256, CRT_SHADE_MIN_WAVES)
+#define CRT_SHADE_BOUNDS __launch_bounds__(kShadeBlock, CRT_SHADE_MIN_WAVES)
 #else
-#define CRT_SHADE_BOUNDS __launch_bounds__(256)
+#define CRT_SHADE_BOUNDS __launch_bounds__(kShadeBlock)
 #endif
 __global__ CRT_SHADE_BOUNDS void k_shade(FrameParams P, FrameBuffers B, SceneView sv, LightsParam LP,
                                                 const uint32_t* count, uint32_t* next_count, uint32_t* shadow_count) {
     /* queue appends are reserved once per BLOCK iteration (LDS partial sums + one atomic per
      * queue): per-wave atomics on the two counters made this kernel atomic-bound */
-    __shared__ uint32_t s_cnt[2][4];
+    __shared__ uint32_t s_cnt[2][kShadeBlock / 64];
     __shared__ uint32_t s_base[2];
     __shared__ double s_ltab[16][2];
     __shared__ unsigned long long s_etab[32];
@@ -1406,7 +1414,7 @@ __global__ CRT_SHADE_BOUNDS void k_shade(FrameParams P, FrameBuffers B, SceneVie
     __syncthreads();
     const uint32_t total = *count;
     const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t rounded = (total + 255u) & ~255u;
+    const uint32_t rounded = (total + (uint32_t)kShadeBlock - 1u) / (uint32_t)kShadeBlock * (uint32_t)kShadeBlock;
     const int raytype = P.bounce > 0 ? 1 : 0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += stride) {
@@ -1534,8 +1542,8 @@ __global__ CRT_SHADE_BOUNDS void k_shade(FrameParams P, FrameBuffers B, SceneVie
         if (lane == 0) { s_cnt[0][wv] = wave_sh; s_cnt[1][wv] = (uint32_t)__popcll(emit_mask); }
         __syncthreads();
         if (threadIdx.x == 0) {
-            const uint32_t tsh = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
-            const uint32_t trf = s_cnt[1][0] + s_cnt[1][1] + s_cnt[1][2] + s_cnt[1][3];
+            uint32_t tsh = 0, trf = 0;
+            for (int w = 0; w < kShadeBlock / 64; w++) { tsh += s_cnt[0][w]; trf += s_cnt[1][w]; }
             s_base[0] = tsh ? atomicAdd(shadow_count, tsh) : 0u;
             s_base[1] = trf ? atomicAdd(next_count, trf) : 0u;
         }
@@ -1627,13 +1635,13 @@ __global__ CRT_SHADE_BOUNDS void k_shade(FrameParams P, FrameBuffers B, SceneVie
 void launch_shade(const FrameParams& fp, const FrameBuffers& fb, const SceneView& sv, const LightsParam& lights,
                   const uint32_t* count, uint32_t* next_count, uint32_t* shadow_count, hipStream_t s) {
     /* grid-stride over the queue; no more blocks than the queue can have entries */
-    uint32_t blocks = (fb.cap + 255u) / 256u;
+    uint32_t blocks = (fb.cap + (uint32_t)kShadeBlock - 1u) / (uint32_t)kShadeBlock;
     /* the kernel is bound by the latency of its dependent gathers (hit slot -> geometry + shading record -> material), not by
      * bytes: more, shorter blocks keep more of them in flight (4096 blocks: 1.60 ms of k_shade + k_resolve per 4K frame,
      * 16384: 1.52; tools/exp/shade_grid.sh) */
     static const uint32_t maxb = [] { const char* v = getenv("CRT_SHADE_BLOCKS"); return v ? (uint32_t)atoi(v) : 16384u; }();
     blocks = blocks < 1u ? 1u : (blocks > maxb ? maxb : blocks);
-    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, s, fp, fb, sv, lights, count, next_count, shadow_count);
+    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kShadeBlock), 0, s, fp, fb, sv, lights, count, next_count, shadow_count);
 }
 
 /* isectPoints[i].color += reflectionCoef * color (Ray.cu:660), colour summed over lights in order
