@@ -74,7 +74,7 @@ bool load_rccl(std::string& err) {
 struct MgpuFrame {
     std::vector<crt_params> p;       /* per rank */
     std::vector<size_t> pb;          /* packed bytes per rank */
-    int fb = 0, kb = 0, slot = 0;    /* frame buffer (rank 0: of 2K + 1, ranks > 0: of K), pack / gather buffer (of 2K), frame slot */
+    int fb = 0, kb = 0, slot = 0;    /* rank 0's frame buffer (of 2K + 1), pack / gather buffer (of 2K), frame slot (the other ranks' frame buffer goes by it) */
 };
 
 struct crt_mgpu {
@@ -136,6 +136,12 @@ int rank_fail(crt_mgpu* m, int rc, const char* what, int r) {
     return mfail(m, rc, std::string(what) + " on rank " + std::to_string(r) + ": " + crt_last_error(m->ctx[r]));
 }
 
+/* Which of a rank's device frames a frame in flight renders into.  Rank 0 keeps 2K + 1 (a frame stays there until its gather is
+ * unpacked and the caller has seen it).  The other ranks only need their frame until the tile pack queued behind the render has
+ * run: one per frame SLOT -- frames in flight never share a slot, whereas seq mod (2K + 1) mod K maps two consecutive frames to
+ * one buffer whenever the sequence wraps. */
+int frame_index(const MgpuFrame& f, int r) { return r == 0 ? f.fb : (f.slot > 0 ? f.slot - 1 : 0); }
+
 /* per-rank parameters, packed sizes and the buffers frame (fb, kb) needs */
 int prepare_frame(crt_mgpu* m, const crt_params* params, MgpuFrame& f) {
     const int R = m->n;
@@ -145,7 +151,7 @@ int prepare_frame(crt_mgpu* m, const crt_params* params, MgpuFrame& f) {
     for (int r = 0; r < R; r++) {
         f.p[r].rank = r; f.p[r].nranks = R;
         f.pb[r] = packed_bytes(&f.p[r], r);
-        const int fb = r == 0 ? f.fb : f.fb % crt_mgpu::K;
+        const int fb = frame_index(f, r);
         if ((rc = ensure_dev(m, m->dev[r], m->frame[r][fb], m->frame_cap[r][fb], fbytes))) return rc;
         if (r > 0 || m->self_exchange) {
             if ((rc = ensure_dev(m, m->dev[r], m->packed[r][f.kb], m->packed_cap[r][f.kb], f.pb[r] ? f.pb[r] : 16))) return rc;
@@ -154,7 +160,7 @@ int prepare_frame(crt_mgpu* m, const crt_params* params, MgpuFrame& f) {
     }
     return CRT_OK;
 }
-void* frame_of(crt_mgpu* m, const MgpuFrame& f, int r) { return m->frame[r][r == 0 ? f.fb : f.fb % crt_mgpu::K]; }
+void* frame_of(crt_mgpu* m, const MgpuFrame& f, int r) { return m->frame[r][frame_index(f, r)]; }
 
 /* queue the frame on every rank's frame slot, each with its tile pack behind it: no waiting */
 int submit_frame(crt_mgpu* m, const crt_camera* cam, MgpuFrame& f) {
@@ -410,7 +416,13 @@ int crt_mgpu_submit(crt_mgpu* m, const crt_camera* cam, const crt_params* params
     f.fb = (int)(m->seq % (crt_mgpu::NB + 1)); f.kb = (int)(m->seq % crt_mgpu::NB); f.slot = 1 + (int)(m->seq % crt_mgpu::K);
     if ((rc = prepare_frame(m, params, f))) return rc;
     for (auto& p : f.p) p.timing = 1;
-    if ((rc = submit_frame(m, cam, f))) return rc;
+    if ((rc = submit_frame(m, cam, f))) {
+        /* the ranks before the failing one hold the frame on this slot: collect it, or the slot stays busy for good */
+        const std::string why = m->err;
+        (void)wait_frame(m, f);
+        m->err = why;
+        return rc;
+    }
     m->inflight.push_back(std::move(f));
     m->seq++;
     return CRT_OK;
@@ -436,7 +448,7 @@ int crt_mgpu_render_device(crt_mgpu* m, const crt_camera* cam, const crt_params*
     if ((rc = prepare_frame(m, params, f))) return rc;
     /* every rank renders and packs its tiles: the submissions return at once, the GPUs work side by side */
     const auto t0 = std::chrono::steady_clock::now();
-    if ((rc = submit_frame(m, cam, f))) { (void)wait_frame(m, f); return rc; }
+    if ((rc = submit_frame(m, cam, f))) { const std::string why = m->err; (void)wait_frame(m, f); m->err = why; return rc; }
     if ((rc = wait_frame(m, f))) return rc;
     const auto t1 = std::chrono::steady_clock::now();
     if ((rc = start_exchange(m, f))) return rc;
