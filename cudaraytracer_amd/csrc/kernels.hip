@@ -968,8 +968,9 @@ bool trace8_has_block(int block) {
 template <int BLOCK>
 static void launch_trace8(const TraceArgs& a, bool counting, int blocks256, hipStream_t s) {
     dim3 g((unsigned)(blocks256 * (256 / BLOCK))), b(BLOCK);      /* the same number of waves whatever the block size */
+    static const bool force_ovf = getenv("CRT_TRACE8_FORCE_OVF") != nullptr;      /* tests: the variant with the overflow code on a shallow tree */
     if (counting) hipLaunchKernelGGL((k_trace8<true, BLOCK, true>), g, b, 0, s, a);
-    else if (a.ovf_depth > 0 || BLOCK != 256) hipLaunchKernelGGL((k_trace8<false, BLOCK, true>), g, b, 0, s, a);
+    else if (a.ovf_depth > 0 || BLOCK != 256 || force_ovf) hipLaunchKernelGGL((k_trace8<false, BLOCK, true>), g, b, 0, s, a);
     else hipLaunchKernelGGL((k_trace8<false, BLOCK, BLOCK != 256>), g, b, 0, s, a);      /* 256 threads, shallow tree: no overflow code */
 }
 

@@ -1,5 +1,6 @@
 """CRT_BVH_WIDE_DEVICE: the device-built tree feeds the same traversal; nearest hits and
 images must equal the oracle's exactly as with the host-built trees (nearest hits do not depend on tree shape)."""
+import os
 import numpy as np
 import pytest
 
@@ -201,3 +202,35 @@ def test_deep_tree_uses_the_stack_overflow_rows(crt, mode):
         assert np.array_equal(ts_g[ids_o >= 0], ts_o[ids_o >= 0])
     finally:
         ctx.close(); sc.close()
+
+
+def test_both_stack_variants_of_the_traversal_agree(tmp_path):
+    """k_trace8<.., OVF>: a tree no deeper than the in-LDS stack runs the variant without the overflow rows; CRT_TRACE8_FORCE_OVF
+    runs the other one on the same tree (a process-wide switch, hence the child processes).  Same frame, same hits."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import cudaraytracer_amd as crt\n"
+        "prims = np.concatenate([crt.scene_soup(40000, seed=3), crt.scene_spheres(500, seed=4)])\n"
+        "ctx = crt.Context(0); ctx.set_scene(prims); ctx.set_lights(crt.default_lights()); ctx.build(0)\n"
+        "assert ctx.stats()['depth'] <= 12\n"
+        "cam, tgt = crt.default_camera()\n"
+        "g = ctx.render(cam, tgt, crt.default_params(width=640, height=360, bounces=3))\n"
+        "rng = np.random.default_rng(1); o = rng.uniform(-150, 150, (100000, 3)); d = rng.normal(size=(100000, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)\n"
+        "ids, ts = ctx.trace(np.concatenate([o, d], axis=1).astype(np.float32))\n"
+        "np.savez(sys.argv[1], g=g, ids=ids, ts=ts)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = []
+    for force in (False, True):
+        env = dict(os.environ)
+        env.pop("CRT_TRACE8_FORCE_OVF", None)
+        if force:
+            env["CRT_TRACE8_FORCE_OVF"] = "1"
+        out = str(tmp_path / f"v{int(force)}.npz")
+        p = subprocess.run([sys.executable, "-c", code, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout
+        outs.append(np.load(out))
+    assert np.array_equal(outs[0]["g"], outs[1]["g"])
+    assert np.array_equal(outs[0]["ids"], outs[1]["ids"]) and np.array_equal(outs[0]["ts"].view(np.uint32), outs[1]["ts"].view(np.uint32))
+    assert (outs[0]["ids"] >= 0).sum() > 10000
