@@ -8,7 +8,7 @@
  * Design (wave64, no MFMA -- nothing here is a dense contraction):
  *   k_trace8     THE traversal kernel (CRT_BVH_WIDE, ~90 % of a frame): persistent waves pull rays from two queues in HBM
  *                (the shadow rays of a bounce and the nearest-hit rays of the next share a launch); each lane walks the
- *                compressed 8-wide tree (QNode8: 80-byte nodes, 8-bit plane codes decoded by v_perm_b32 + v_fma_mix_f32,
+ *                compressed 8-wide tree (QNode8: 80-byte nodes, 8-bit plane codes decoded and near/far-selected by v_perm_b32, used by v_fma_mix_f32,
  *                an inline-asm slab test yielding a hit MASK, no distance sort) with one 64-bit stack entry per level in
  *                LDS (stack[depth][lane]); the wave votes between a node step and a primitive step each iteration; rays are
  *                fetched in XCD-affine chunks; a second instantiation of the loop shares the work of a wave's last rays
@@ -388,12 +388,13 @@ __global__ CRT_TRACE_BOUNDS void k_trace(TraceArgs A) {
  * Scheduling (wave vote between node steps and primitive steps, chunked XCD-affine ray fetch,
  * per-lane stack rows in LDS) is the same as in k_trace.
  * ------------------------------------------------------------------------------------------ */
-/* Slab test of one child of a QNode8.  The six plane codes arrive as fp16 values 1024 + q -- the
- * byte q under the constant high byte 0x64, two codes per word, assembled by ONE v_perm_b32 per
- * word -- so a plane distance is ONE v_fma_mix_f32 (fp16 x fp32 + fp32) instead of
- * v_cvt_f32_ubyte + v_fma_f32; the node origin is stored shifted by -1024 s to match.  HI picks the
- * upper half of the words.  The whole ten-instruction sequence is written out because the
- * compiler canonicalises (v_max_f32 x,x) every asm result that feeds fmaxf/fminf.
+/* Slab test of one child of a QNode8.  The six plane codes arrive as fp16 DENORMALS -- the byte q under a zero high byte,
+ * q * 2^-24, two codes per word, assembled by ONE v_perm_b32 per word whose per-ray selector also picks the lo or the hi row
+ * (near / far) -- so a plane distance is ONE v_fma_mix_f32 (fp16 x fp32 + fp32) instead of v_cvt_f32_ubyte + v_fma_f32; the
+ * stored scale exponent carries the 2^24 (layout.h kQ8ScaleShift).  Until round 3 the codes were 1024 + q under the constant
+ * byte 0x64 and the rows were selected by twelve v_cndmask + three v_cmp per node step.  HI picks the upper half of the words.
+ * The whole ten-instruction sequence is written out because the compiler canonicalises (v_max_f32 x,x) every asm result that
+ * feeds fmaxf/fminf.
  *   tn = max(tnx, tny, tnz, -1.0001e-4)      tf = min(tfx, tfy, tfz, tbest)      raw = 2 raw + (tn <= tf)
  * (v_addc_co_u32 shifts the hit bit in through the per-lane carry: children are tested 7 .. 0). */
 template <bool HI>
@@ -499,6 +500,10 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
     vec3 o, d;
     float ix = 0, iy = 0, iz = 0, anx = 0, afx = 0, any_ = 0, afy = 0, anz = 0, afz = 0;
     uint32_t R = 0;
+    /* v_perm selector of the NEAR plane codes of children 2,3 / 6,7 of an axis: bytes 2,3 of the hi row (second v_perm operand)
+     * for a negative direction, of the lo row (first operand) for a positive one, each under a zero high byte.  far = ^ 0x00040004,
+     * children 0,1 / 4,5 = - 0x00020002 */
+    uint32_t selx = 0, sely = 0, selz = 0;
     float tbest = 0;
     int best = -1;
     uint32_t ray = 0;
@@ -594,6 +599,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                     o = vec3(c_ox, c_oy, c_oz); d = vec3(c_dx, c_dy, c_dz);
                     ix = c_ix; iy = c_iy; iz = c_iz; anx = c_anx; afx = c_afx; any_ = c_any; afy = c_afy; anz = c_anz; afz = c_afz;
                     tbest = c_tb; best = c_best; R = c_R; ray = c_ray; lkind = c_lk;
+                    selx = (c_R & 4u) ? 0x0c070c06u : 0x0c030c02u; sely = (c_R & 2u) ? 0x0c070c06u : 0x0c030c02u; selz = (c_R & 1u) ? 0x0c070c06u : 0x0c030c02u;
                     const uint32_t vnst = (c_fs >> 16) & 15u;
                     const uint2 e = s_stack[vnst][wbase + v];
                     gbase = e.x; gmask = e.y;
@@ -723,36 +729,35 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                         const float bnx = fmaf(nox, ix, -anx), bfx = fmaf(nox, ix, -afx);
                         const float bny = fmaf(noy, iy, -any_), bfy = fmaf(noy, iy, -afy);
                         const float bnz = fmaf(noz, iz, -anz), bfz = fmaf(noz, iz, -afz);
-                        /* near / far rows by the sign of the direction: children 0-3 in word 0, 4-7 in word 1 */
-                        const bool ngx = ix < 0.f, ngy = iy < 0.f, ngz = iz < 0.f;
-                        const uint32_t nx0 = ngx ? PX.z : PX.x, nx1 = ngx ? PX.w : PX.y, fx0 = ngx ? PX.x : PX.z, fx1 = ngx ? PX.y : PX.w;
-                        const uint32_t ny0 = ngy ? PY.z : PY.x, ny1 = ngy ? PY.w : PY.y, fy0 = ngy ? PY.x : PY.z, fy1 = ngy ? PY.y : PY.w;
-                        const uint32_t nz0 = ngz ? PZ.z : PZ.x, nz1 = ngz ? PZ.w : PZ.y, fz0 = ngz ? PZ.x : PZ.z, fz1 = ngz ? PZ.y : PZ.w;
+                        /* rows: PX = lo_x[0..3] lo_x[4..7] hi_x[0..3] hi_x[4..7].  One v_perm_b32 per pair of codes takes them from the
+                         * lo or the hi row as the ray's selector says (near / far) and puts each under a zero byte: fp16 denormals
+                         * q * 2^-24, which v_fma_mix_f32 multiplies by the scale (stored with 2^24 folded in) */
+                        const uint32_t nX23 = selx, fX23 = selx ^ 0x00040004u, nX01 = selx - 0x00020002u, fX01 = fX23 - 0x00020002u;
+                        const uint32_t nY23 = sely, fY23 = sely ^ 0x00040004u, nY01 = sely - 0x00020002u, fY01 = fY23 - 0x00020002u;
+                        const uint32_t nZ23 = selz, fZ23 = selz ^ 0x00040004u, nZ01 = selz - 0x00020002u, fZ01 = fZ23 - 0x00020002u;
                         uint32_t raw = 0;
-                        /* bytes (q_a, q_b) of a row word -> fp16 pair (1024 + q_a, 1024 + q_b): byte 4 of the
-                         * v_perm source is the constant 0x64 */
-#define PAIR01(W) __builtin_amdgcn_perm(0x64646464u, (W), 0x04010400u)
-#define PAIR23(W) __builtin_amdgcn_perm(0x64646464u, (W), 0x04030402u)
-#define SLAB8x4(RAW, TB, NXW, FXW, NYW, FYW, NZW, FZW)                                                                 \
+#define SLAB8x4(RAW, TB, LOX, HIX, LOY, HIY, LOZ, HIZ)                                                                 \
     {                                                                                                         \
-        const uint32_t c0 = PAIR23(NXW), c1 = PAIR23(FXW), c2 = PAIR23(NYW), c3 = PAIR23(FYW), c4 = PAIR23(NZW), c5 = PAIR23(FZW); \
+        const uint32_t c0 = __builtin_amdgcn_perm(LOX, HIX, nX23), c1 = __builtin_amdgcn_perm(LOX, HIX, fX23),             \
+                       c2 = __builtin_amdgcn_perm(LOY, HIY, nY23), c3 = __builtin_amdgcn_perm(LOY, HIY, fY23),             \
+                       c4 = __builtin_amdgcn_perm(LOZ, HIZ, nZ23), c5 = __builtin_amdgcn_perm(LOZ, HIZ, fZ23);             \
         slab8<true>(RAW, c0, c1, c2, c3, c4, c5, sx, sy, sz, bnx, bfx, bny, bfy, bnz, bfz, TB);            \
         slab8<false>(RAW, c0, c1, c2, c3, c4, c5, sx, sy, sz, bnx, bfx, bny, bfy, bnz, bfz, TB);           \
-        const uint32_t a0 = PAIR01(NXW), a1 = PAIR01(FXW), a2 = PAIR01(NYW), a3 = PAIR01(FYW), a4 = PAIR01(NZW), a5 = PAIR01(FZW); \
+        const uint32_t a0 = __builtin_amdgcn_perm(LOX, HIX, nX01), a1 = __builtin_amdgcn_perm(LOX, HIX, fX01),             \
+                       a2 = __builtin_amdgcn_perm(LOY, HIY, nY01), a3 = __builtin_amdgcn_perm(LOY, HIY, fY01),             \
+                       a4 = __builtin_amdgcn_perm(LOZ, HIZ, nZ01), a5 = __builtin_amdgcn_perm(LOZ, HIZ, fZ01);             \
         slab8<true>(RAW, a0, a1, a2, a3, a4, a5, sx, sy, sz, bnx, bfx, bny, bfy, bnz, bfz, TB);            \
         slab8<false>(RAW, a0, a1, a2, a3, a4, a5, sx, sy, sz, bnx, bfx, bny, bfy, bnz, bfz, TB);           \
     }
-                        SLAB8x4(raw, tbest, nx1, fx1, ny1, fy1, nz1, fz1)      /* children 7, 6, 5, 4 */
-                        SLAB8x4(raw, tbest, nx0, fx0, ny0, fy0, nz0, fz0)      /* children 3, 2, 1, 0 */
+                        SLAB8x4(raw, tbest, PX.y, PX.w, PY.y, PY.w, PZ.y, PZ.w)      /* children 7, 6, 5, 4 */
+                        SLAB8x4(raw, tbest, PX.x, PX.z, PY.x, PY.z, PZ.x, PZ.z)      /* children 3, 2, 1, 0 */
                         uint32_t raw_far = 0;            /* counting only: what the visit would have hit without the t limit */
                         if (COUNT) {
                             const float tinf = INFINITY;
-                            SLAB8x4(raw_far, tinf, nx1, fx1, ny1, fy1, nz1, fz1)
-                            SLAB8x4(raw_far, tinf, nx0, fx0, ny0, fy0, nz0, fz0)
+                            SLAB8x4(raw_far, tinf, PX.y, PX.w, PY.y, PY.w, PZ.y, PZ.w)
+                            SLAB8x4(raw_far, tinf, PX.x, PX.z, PY.x, PY.z, PZ.x, PZ.z)
                         }
 #undef SLAB8x4
-#undef PAIR01
-#undef PAIR23
                         const uint32_t vmask = h1.x >> 24, imask = em >> 24;
                         raw &= vmask;                       /* an empty slot can pass the padded test of a degenerate node */
                         if (COUNT) { nbox[ray >> 31] += (unsigned long long)__popc(vmask); nvis[ray >> 31]++; if (raw == 0u) nzero++; if ((ray >> 31) && (fstate & 1u)) nstale++;
@@ -904,6 +909,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                 any_ = (ngy ? o.y - py : o.y + py) * iy; afy = (ngy ? o.y + py : o.y - py) * iy;
                 anz = (ngz ? o.z - pz : o.z + pz) * iz; afz = (ngz ? o.z + pz : o.z - pz) * iz;
                 R = (ngx ? 0u : 4u) | (ngy ? 0u : 2u) | (ngz ? 0u : 1u);
+                selx = ngx ? 0x0c030c02u : 0x0c070c06u; sely = ngy ? 0x0c030c02u : 0x0c070c06u; selz = ngz ? 0x0c030c02u : 0x0c070c06u;
                 tbest = 1000000000.0f; best = -1; sp = 0; fstate = (uint32_t)lane << 8; lp = lend = 0; plm = 0;
                 gbase = 0; gmask = (1u << 8) | (1u << R);      /* a group whose only child is the root */
                 active = true;
@@ -1036,7 +1042,6 @@ __global__ __launch_bounds__(256) void k_quantize8(const Node8* nodes, uint32_t 
             nint++;
         }
     }
-    if (bad || cbase >= (1u << 24) || pb >= (1u << 24)) atomicOr(status, 2u);     /* both bases share a word with an 8-bit mask */
     float org[3];
     uint32_t ex[3];
     for (int a = 0; a < 3; a++) {
@@ -1053,8 +1058,8 @@ __global__ __launch_bounds__(256) void k_quantize8(const Node8* nodes, uint32_t 
         (void)frexpf(ext / (float)(kQ8Grid - 1), &e);
         float sc = ldexpf(1.0f, e);
         if (!(ext > 0.f)) sc = ldexpf(1.0f, -60);
-        /* the traversal reads a code q as the fp16 value 1024 + q (slab8 above), so the stored origin
-         * is os = o - 1024 s and a plane sits at os + (1024 + q) s; the containment check uses exactly that */
+        /* the traversal reads a code q as kQ8Bias + q (0 since the codes became fp16 denormals, slab8 above; 1024 before), so the
+         * stored origin is os = o - kQ8Bias s and a plane sits at os + (kQ8Bias + q) s; the containment check uses exactly that */
         float os = o;
         for (int attempt = 0; attempt < 4; attempt++) {
             bool fits = true;
@@ -1077,9 +1082,11 @@ __global__ __launch_bounds__(256) void k_quantize8(const Node8* nodes, uint32_t 
             if (fits) break;
             sc *= 2.0f;
         }
-        ex[a] = (__float_as_uint(sc) >> 23) & 0xffu;
+        ex[a] = ((__float_as_uint(sc) >> 23) & 0xffu) + kQ8ScaleShift;      /* < 255: sc <= the scene's extent */
+        if (ex[a] > 254u) bad = true;
         org[a] = os;
     }
+    if (bad || cbase >= (1u << 24) || pb >= (1u << 24)) atomicOr(status, 2u);     /* both bases share a word with an 8-bit mask */
     q.ox = org[0]; q.oy = org[1]; q.oz = org[2];
     q.exps_imask = ex[0] | (ex[1] << 8) | (ex[2] << 16) | (imask << 24);
     q.base_vmask = cbase | (vmask << 24);

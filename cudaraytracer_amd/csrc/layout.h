@@ -90,7 +90,11 @@ struct alignas(16) QNode8 {
 };
 static_assert(sizeof(QNode8) == 80, "QNode8 must be 80 bytes");
 constexpr int kQ8Grid = 255;            /* largest plane code */
-constexpr uint32_t kQ8Bias = 1024;      /* a code q is read as the fp16 value 1024 + q (bits 0x6400 | q): ox/oy/oz hold o - 1024 s */
+/* A code q reaches the traversal's v_fma_mix_f32 as the fp16 value with bits 0x00:q -- a DENORMAL, q * 2^-24 exactly (fp16
+ * denormals are on: .amdhsa_float_denorm_mode_16_64 3) -- so that the byte can come from either row word through one v_perm_b32
+ * whose selector also says which row (near / far by the ray's direction); the stored scale exponent carries the 2^24 back. */
+constexpr uint32_t kQ8Bias = 0;
+constexpr uint32_t kQ8ScaleShift = 24;
 constexpr int kWide8LeafMax = 4;        /* primitives per leaf of the wide tree (2 bits in meta) */
 
 struct alignas(16) Geom { float w[12]; };
