@@ -37,6 +37,13 @@ namespace crt {
  * SGPRs with v_cndmask_b32 + v_cmp_ne_u32 -- two half-rate VALU instructions per vote, ten per iteration of the traversal
  * loops; the intrinsic on the i1 is one s_and_b64 with exec. */
 #define crt_ballot(P) __builtin_amdgcn_ballot_w64((bool)(P))
+/* population count of a lane mask on the scalar unit, as a 32-bit value: __popcll's 64-bit result drew 64-bit compares, which
+ * exist only on the vector unit */
+static __device__ __forceinline__ int popc_mask(unsigned long long m) {
+    int r;
+    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(r) : "s"(m) : "scc");
+    return r;
+}
 
 static_assert(kFetchChunk >= 1 && (kFetchChunk & (kFetchChunk - 1)) == 0, "CRT_FETCH_CHUNK must be a power of two");
 constexpr uint32_t kRegionAlign = kFetchChunk > 64 ? (uint32_t)kFetchChunk : 64u;      /* region size granule: a multiple of the chunk and of a wave */
@@ -514,7 +521,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
     /* bit 0: a shadow ray has found an occluder with t > 1e-9; bit 1: a directional shadow ray met a hit with t <= 1e-9 (lit,
      * overrides); bits 8-13: the lane that owns the ray; bits 16-19: stack entries given away from the bottom; bit 24: the
      * ray is shared with other lanes of the wave (result goes through s_key / s_cnt) */
-    uint32_t fstate = 0;
+    uint32_t fstate = 1u << 31;          /* kIdle, below */
     uint32_t tick = 0;
     uint32_t lkind = kShadowDirectional;   /* shadow lanes: float bits of the ray's light distance (kernels.h) */
     unsigned long long nbox[2] = {0, 0}, ntri[2] = {0, 0}, nsph[2] = {0, 0}, nvis[2] = {0, 0};      /* [0] nearest-hit rays, [1] shadow rays */
@@ -553,6 +560,9 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
      * in the finishing iteration ran the write-out for one or two lanes in a third of all iterations; a finished lane idles until
      * the next refill anyway, so the result is written when the lane is set up for its next ray (or when the queue runs dry) */
     constexpr uint32_t kZombie = 1u << 25;
+    /* fstate bit 31 == !active, kept beside the bool: the loop's vote on "which lanes have a ray" is then one signed compare of a
+     * VGPR; a vote on the loop-carried bool costs two VALU instructions (the compiler rebuilds its lane mask through a VGPR) */
+    constexpr uint32_t kIdle = 1u << 31;
 #define CRT_MARK8(NAME) if constexpr (!TAIL) { CRT_MARK(NAME) }
     auto iteration = [&](auto tail_tag) __attribute__((always_inline)) -> bool {
         constexpr bool TAIL = decltype(tail_tag)::value;
@@ -562,9 +572,9 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
          *      loads return later (loads return in order), so the refill costs the wave no extra stall ---- */
         bool pend = false, pend_sh = false;
         float4 pro4, prd;      /* read only by the lanes that set pend; a ray record carries its own index / result slot in .w of its origin */
-        /* one vote on `active` serves the refill trigger, the "anything to do" test and the node count below: every
-         * vote on a bool costs two VALU instructions (the compiler rebuilds the lane mask through a VGPR) */
-        const unsigned long long amask = crt_ballot(active);
+        /* one vote on `active` serves the refill trigger, the "anything to do" test and the node count below */
+        const unsigned long long amask = crt_ballot((int32_t)fstate >= 0);
+        const int nactive = popc_mask(amask);
         if constexpr (TAIL) {
         if (COUNT && lane == 0) itc[7]++;
         /* ---- steal: the queue is dry and this wave is draining.  A launch ends when its longest ray does (a chain of a few
@@ -619,7 +629,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
         if constexpr (!TAIL)
         if (!exhausted) {
             const unsigned long long idle = ~amask;
-            const int nidle = 64 - __popcll(amask);
+            const int nidle = 64 - nactive;
             if (nidle >= kRefillMinIdle8) {
                 if (COUNT && lane == 0) itc[1]++;
                 if (cnext >= cend) {
@@ -678,10 +688,12 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
         if (COUNT && lane == 0) itc[0]++;
         if (amask != 0ull) {
             CRT_MARK8("vote_begin")
-            const bool want_prim = active && (lp < lend || plm >= (1u << 24));
+            /* a lane without a ray has lp == lend == 0 and plm == 0 (set where `active` is cleared), and lp <= lend always:
+             * one compare on one value, which the vote takes as its lane mask without a detour through a VGPR */
+            const bool want_prim = ((lend - lp) | (plm >> 24)) != 0u;
             const bool want_node = active && !want_prim;
-            const int n_prim = __popcll(crt_ballot(want_prim));
-            const int n_node = __popcll(amask) - n_prim;
+            const int n_prim = popc_mask(crt_ballot(want_prim));
+            const int n_node = nactive - n_prim;
             bool finish = false;
             if (COUNT && lane == 0) {     /* scheduling statistics: [8] node iterations [9] lanes served [10] prim iterations [11] lanes served [12] active lanes */
                 if (n_node * CRT_VOTE8_PRIM_WEIGHT >= n_prim * CRT_VOTE8_NODE_WEIGHT) { sch[0]++; sch[1] += n_node; } else { sch[2]++; sch[3] += n_prim; }
@@ -871,7 +883,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                     }
                 } else if constexpr (TAIL) write_result();
                 else fstate |= kZombie;          /* main loop: the result is written when the lane takes its next ray (refill2) */
-                active = false; lp = lend = 0; plm = 0;
+                active = false; fstate |= kIdle; lp = lend = 0; plm = 0;
             }
             CRT_MARK8("finish_end")
         }
