@@ -506,10 +506,10 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
     uint32_t region_k = 0;
     vec3 o, d;
     float ix = 0, iy = 0, iz = 0, anx = 0, afx = 0, any_ = 0, afy = 0, anz = 0, afz = 0;
-    uint32_t R = 0;
+    uint32_t R = 0;        /* bit 2 / 1 / 0: the direction is NEGATIVE along x / y / z; child slot ^ R = its place in front-to-back order */
     /* v_perm selector of the NEAR plane codes of children 2,3 / 6,7 of an axis: bytes 2,3 of the hi row (second v_perm operand)
-     * for a negative direction, of the lo row (first operand) for a positive one, each under a zero high byte.  far = ^ 0x00040004,
-     * children 0,1 / 4,5 = - 0x00020002 */
+     * for a negative direction, of the lo row (first operand) for a positive one, each under a zero high byte.  The far codes come
+     * from the same selector with the two rows swapped; children 0,1 / 4,5 = - 0x00020002 */
     uint32_t selx = 0, sely = 0, selz = 0;
     float tbest = 0;
     int best = -1;
@@ -609,7 +609,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                     o = vec3(c_ox, c_oy, c_oz); d = vec3(c_dx, c_dy, c_dz);
                     ix = c_ix; iy = c_iy; iz = c_iz; anx = c_anx; afx = c_afx; any_ = c_any; afy = c_afy; anz = c_anz; afz = c_afz;
                     tbest = c_tb; best = c_best; R = c_R; ray = c_ray; lkind = c_lk;
-                    selx = (c_R & 4u) ? 0x0c070c06u : 0x0c030c02u; sely = (c_R & 2u) ? 0x0c070c06u : 0x0c030c02u; selz = (c_R & 1u) ? 0x0c070c06u : 0x0c030c02u;
+                    selx = (c_R & 4u) ? 0x0c030c02u : 0x0c070c06u; sely = (c_R & 2u) ? 0x0c030c02u : 0x0c070c06u; selz = (c_R & 1u) ? 0x0c030c02u : 0x0c070c06u;
                     const uint32_t vnst = (c_fs >> 16) & 15u;
                     const uint2 e = s_stack[vnst][wbase + v];
                     gbase = e.x; gmask = e.y;
@@ -718,9 +718,11 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                     }
                     CRT_MARK8("pop_end")
                     if (!finish && (!TAIL || (gmask & 0xffu) != 0u)) {          /* tail: a popped entry is empty when its group was given to another lane */
-                        const uint32_t pbit = 31u - (uint32_t)__builtin_clz(gmask & 0xffu);      /* not zero here: no guard for clz(0) */
+                        /* pending children sit in visiting order from bit 0 up (bit = slot ^ R, R = the NEGATIVE directions): the next
+                         * one is the lowest set bit, taken and cleared without building a mask (bits 0-7 are not all zero here) */
+                        const uint32_t pbit = (uint32_t)__builtin_ctz(gmask);
                         const uint32_t slot = pbit ^ R;
-                        gmask ^= 1u << pbit;
+                        gmask &= gmask - 1u;
                         const uint32_t node = gbase + (uint32_t)__popc((gmask >> 8) & ((1u << slot) - 1u));
                         if (gmask & 0xffu) {
                             if (!OVF || sp < kDepth) s_stack[sp][tid] = make_uint2(gbase, gmask);
@@ -744,20 +746,22 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                         /* rows: PX = lo_x[0..3] lo_x[4..7] hi_x[0..3] hi_x[4..7].  One v_perm_b32 per pair of codes takes them from the
                          * lo or the hi row as the ray's selector says (near / far) and puts each under a zero byte: fp16 denormals
                          * q * 2^-24, which v_fma_mix_f32 multiplies by the scale (stored with 2^24 folded in) */
-                        const uint32_t nX23 = selx, fX23 = selx ^ 0x00040004u, nX01 = selx - 0x00020002u, fX01 = fX23 - 0x00020002u;
-                        const uint32_t nY23 = sely, fY23 = sely ^ 0x00040004u, nY01 = sely - 0x00020002u, fY01 = fY23 - 0x00020002u;
-                        const uint32_t nZ23 = selz, fZ23 = selz ^ 0x00040004u, nZ01 = selz - 0x00020002u, fZ01 = fZ23 - 0x00020002u;
-                        uint32_t raw = 0;
+                        /* the far plane comes from the other row: the same selector with the two rows swapped */
+                        const uint32_t X23 = selx, X01 = selx - 0x00020002u;
+                        const uint32_t Y23 = sely, Y01 = sely - 0x00020002u;
+                        const uint32_t Z23 = selz, Z01 = selz - 0x00020002u;
+                        uint32_t raw;        /* eight compare results are shifted in; whatever was there ends above bit 7, which every use masks off */
+                        if (COUNT) raw = 0; else asm volatile("" : "=v"(raw));
 #define SLAB8x4(RAW, TB, LOX, HIX, LOY, HIY, LOZ, HIZ)                                                                 \
     {                                                                                                         \
-        const uint32_t c0 = __builtin_amdgcn_perm(LOX, HIX, nX23), c1 = __builtin_amdgcn_perm(LOX, HIX, fX23),             \
-                       c2 = __builtin_amdgcn_perm(LOY, HIY, nY23), c3 = __builtin_amdgcn_perm(LOY, HIY, fY23),             \
-                       c4 = __builtin_amdgcn_perm(LOZ, HIZ, nZ23), c5 = __builtin_amdgcn_perm(LOZ, HIZ, fZ23);             \
+        const uint32_t c0 = __builtin_amdgcn_perm(LOX, HIX, X23), c1 = __builtin_amdgcn_perm(HIX, LOX, X23),             \
+                       c2 = __builtin_amdgcn_perm(LOY, HIY, Y23), c3 = __builtin_amdgcn_perm(HIY, LOY, Y23),             \
+                       c4 = __builtin_amdgcn_perm(LOZ, HIZ, Z23), c5 = __builtin_amdgcn_perm(HIZ, LOZ, Z23);             \
         slab8<true>(RAW, c0, c1, c2, c3, c4, c5, sx, sy, sz, bnx, bfx, bny, bfy, bnz, bfz, TB);            \
         slab8<false>(RAW, c0, c1, c2, c3, c4, c5, sx, sy, sz, bnx, bfx, bny, bfy, bnz, bfz, TB);           \
-        const uint32_t a0 = __builtin_amdgcn_perm(LOX, HIX, nX01), a1 = __builtin_amdgcn_perm(LOX, HIX, fX01),             \
-                       a2 = __builtin_amdgcn_perm(LOY, HIY, nY01), a3 = __builtin_amdgcn_perm(LOY, HIY, fY01),             \
-                       a4 = __builtin_amdgcn_perm(LOZ, HIZ, nZ01), a5 = __builtin_amdgcn_perm(LOZ, HIZ, fZ01);             \
+        const uint32_t a0 = __builtin_amdgcn_perm(LOX, HIX, X01), a1 = __builtin_amdgcn_perm(HIX, LOX, X01),             \
+                       a2 = __builtin_amdgcn_perm(LOY, HIY, Y01), a3 = __builtin_amdgcn_perm(HIY, LOY, Y01),             \
+                       a4 = __builtin_amdgcn_perm(LOZ, HIZ, Z01), a5 = __builtin_amdgcn_perm(HIZ, LOZ, Z01);             \
         slab8<true>(RAW, a0, a1, a2, a3, a4, a5, sx, sy, sz, bnx, bfx, bny, bfy, bnz, bfz, TB);            \
         slab8<false>(RAW, a0, a1, a2, a3, a4, a5, sx, sy, sz, bnx, bfx, bny, bfy, bnz, bfz, TB);           \
     }
@@ -920,7 +924,7 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                 anx = (ngx ? o.x - px : o.x + px) * ix; afx = (ngx ? o.x + px : o.x - px) * ix;
                 any_ = (ngy ? o.y - py : o.y + py) * iy; afy = (ngy ? o.y + py : o.y - py) * iy;
                 anz = (ngz ? o.z - pz : o.z + pz) * iz; afz = (ngz ? o.z + pz : o.z - pz) * iz;
-                R = (ngx ? 0u : 4u) | (ngy ? 0u : 2u) | (ngz ? 0u : 1u);
+                R = (ngx ? 4u : 0u) | (ngy ? 2u : 0u) | (ngz ? 1u : 0u);
                 selx = ngx ? 0x0c030c02u : 0x0c070c06u; sely = ngy ? 0x0c030c02u : 0x0c070c06u; selz = ngz ? 0x0c030c02u : 0x0c070c06u;
                 tbest = 1000000000.0f; best = -1; sp = 0; fstate = (uint32_t)lane << 8; lp = lend = 0; plm = 0;
                 gbase = 0; gmask = (1u << 8) | (1u << R);      /* a group whose only child is the root */
