@@ -157,9 +157,11 @@ struct RefBuilder {
     }
 };
 
-inline void prim_bounds(const crt_prim& o, float lo[3], float hi[3]) {
+/* box of a primitive in the wide tree: a sphere's holds the ball its hit predicate can reach (layout.h sphere_box_half) */
+inline void prim_bounds(const crt_prim& o, float origin_bound, float lo[3], float hi[3]) {
     if (o.type == 0) {
-        for (int a = 0; a < 3; a++) { lo[a] = o.position[a] - o.radius; hi[a] = o.position[a] + o.radius; }
+        const float hs = sphere_box_half(o.position[0], o.position[1], o.position[2], o.radius, origin_bound);
+        for (int a = 0; a < 3; a++) { lo[a] = o.position[a] - hs; hi[a] = o.position[a] + hs; }
     } else {
         for (int a = 0; a < 3; a++) {
             lo[a] = std::min(o.v1[a], std::min(o.v2[a], o.v3[a]));
@@ -402,6 +404,19 @@ struct WideBuilder {
 
 }  // namespace
 
+/* |o| of every ray that starts inside the scene or inside the reference's room (walls at +-200, +-200, +-300, Ray.cu:238-457):
+ * sqrt(3) x the largest coordinate of either.  Only sets where the cost of sphere_box_half's cancellation noise goes -- into the
+ * sphere boxes (rays from inside) or into the ray's own pad (rays from further out); any value is correct */
+float origin_bound_of(const crt_prim* prims, int n) {
+    float m = 300.f;
+    for (int i = 0; i < n; i++) {
+        const crt_prim& o = prims[i];
+        if (o.type == 0) { for (int a = 0; a < 3; a++) m = std::max(m, std::fabs(o.position[a]) + o.radius); }
+        else for (int a = 0; a < 3; a++) m = std::max(m, std::max(std::fabs(o.v1[a]), std::max(std::fabs(o.v2[a]), std::fabs(o.v3[a]))));
+    }
+    return 1.7320509f * 1.001f * m;
+}
+
 int build_wide(const crt_prim* prims, int n, const RefTree* ref, HostBVH& out) {
     out.nodes.clear(); out.nodes8.clear(); out.mode = CRT_BVH_WIDE; out.depth = 0; out.leaves = 0;
     out.slot_to_scene.clear(); out.slot_to_scene.reserve(n);
@@ -409,9 +424,10 @@ int build_wide(const crt_prim* prims, int n, const RefTree* ref, HostBVH& out) {
     if (ref) ranks_from(*ref, n, out.rank_of_scene);
     else { out.rank_of_scene.resize(n); for (int i = 0; i < n; i++) out.rank_of_scene[i] = (uint32_t)i; }
 
+    out.origin_bound = origin_bound_of(prims, n);
     std::vector<PrimRef> refs(n);
     for (int i = 0; i < n; i++) {
-        prim_bounds(prims[i], refs[i].box.lo, refs[i].box.hi);
+        prim_bounds(prims[i], out.origin_bound, refs[i].box.lo, refs[i].box.hi);
         for (int a = 0; a < 3; a++) refs[i].c[a] = 0.5f * (refs[i].box.lo[a] + refs[i].box.hi[a]);
         refs[i].idx = i;
     }

@@ -42,6 +42,7 @@ struct HostBVH {
     std::vector<uint32_t> slot_to_scene;
     std::vector<uint32_t> rank_of_scene;   /* reference leaf-order position of each scene index */
     float root_box[6];
+    float origin_bound = 0.f;      /* wide trees: what the sphere boxes were padded for (layout.h sphere_box_half) */
     int depth = 0, leaves = 0, mode = 0;
 };
 
@@ -50,6 +51,7 @@ int build_reference_tree(const crt_prim* prims, int n, RefTree& out);
 void refit_reference_tree(const crt_prim* prims, RefTree& t);          /* bvh.cu:288-400 on the index tree */
 int pack_reference(const crt_prim* prims, int n, const RefTree& t, HostBVH& out);
 int build_wide(const crt_prim* prims, int n, const RefTree* ref_or_null, HostBVH& out);
+float origin_bound_of(const crt_prim* prims, int n);
 
 }  // namespace crt
 #endif

@@ -57,7 +57,7 @@ struct FrameSlot {
      * contents changes */
     struct GraphKey {
         crt_camera cam; crt_params p; LightsParam lights;
-        const void* ptrs[20]; uint32_t nnodes, nprims, nmats, depth, mode; int counting, capture, grid, ovf_depth, block, keep_zero; float scene_abs;
+        const void* ptrs[20]; uint32_t nnodes, nprims, nmats, depth, mode; int counting, capture, grid, ovf_depth, block, keep_zero; float scene_abs, origin_bound;
     };
     GraphKey graph_key{}; hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; bool in_capture = false;
     uint8_t* d_bgr = nullptr; size_t bgr_cap = 0;
@@ -108,6 +108,7 @@ struct crt_ctx {
     crt_prim* d_prims = nullptr; uint32_t* d_matid = nullptr; size_t prim_cap = 0;
     uint32_t* d_arrive = nullptr; size_t arrive_cap = 0;
     float scene_abs = 0.f;
+    float origin_bound_scene = 0.f;      /* origin_bound_of(prims) as of crt_scene_set / crt_scene_update: what the next device build pads sphere boxes for */
 
     /* frames: every slot owns a stream and a full set of per-frame buffers, so that up to CRT_MAX_FRAME_SLOTS frames
      * (or tile subsets of one frame) are in flight at once on the read-only scene blob.  Slot 0 runs on the context's own
@@ -493,7 +494,7 @@ int ctx_refit_enqueue(crt_ctx* c, int grow_only) {
     f0.evused -= 2;
     HIPCHECK(c, hipEventRecord(c->refit_ev[0], c->stream));
     if (c->hdr.mode == CRT_BVH_WIDE) {
-        launch_refit8((Node8*)(b + c->hdr.off_nodes), c->hdr.nnodes, (const Geom*)(b + c->hdr.off_geom), c->d_arrive,
+        launch_refit8((Node8*)(b + c->hdr.off_nodes), c->hdr.nnodes, (const Geom*)(b + c->hdr.off_geom), c->hdr.origin_bound, c->d_arrive,
                       (float*)(b + offsetof(BlobHeader, root_box)), grow_only ? 1 : 0, c->stream);
         launch_quantize((const Node8*)(b + c->hdr.off_nodes), c->hdr.nnodes, (QNode8*)(b + c->hdr.off_qnodes), c->d_status, c->stream);
     } else {
@@ -526,7 +527,7 @@ int ctx_trace_view(crt_ctx* c, TraceView* v) {
     v->built = c->built;
     v->sv = c->built ? view_of(c) : SceneView{};
     v->stream = c->stream; v->device = c->device; v->wide = c->hdr.mode == CRT_BVH_WIDE;
-    v->scene_abs = c->scene_abs; v->ovf = c->d_ovf; v->ovf_depth = c->ovf_depth;
+    v->scene_abs = c->scene_abs; v->origin_bound = c->hdr.origin_bound; v->ovf = c->d_ovf; v->ovf_depth = c->ovf_depth;
     v->counters = c->d_testctr; v->status = c->d_status; v->h_status = c->h_status; v->grid_blocks = c->grid_blocks; v->block = c->trace_block;
     return CRT_OK;
 }
@@ -622,6 +623,7 @@ int crt_scene_set(crt_ctx* c, const crt_prim* prims, int n) {
     c->prims.assign(prims, prims + n);
     dedupe_materials(c);
     c->nonfinite_scene = shading_may_be_nonfinite(c->prims);
+    c->origin_bound_scene = origin_bound_of(c->prims.data(), n);
     c->built = false; c->have_ref = false; c->imported = false; c->host_stale = false;
     return upload_prims(c);
 }
@@ -647,6 +649,7 @@ int crt_scene_update(crt_ctx* c, const crt_prim* prims, int n) {
     int rc = upload_prims(c);
     if (rc) return rc;
     c->nonfinite_scene = shading_may_be_nonfinite(c->prims);          /* radii and normals moved */
+    c->origin_bound_scene = origin_bound_of(c->prims.data(), n);      /* for the next device build; the current tree keeps the bound it was built for */
     if (c->built && ((c->hdr.flags & kBlobNonFiniteShading) != 0u) != c->nonfinite_scene) {
         c->hdr.flags = (c->hdr.flags & ~kBlobNonFiniteShading) | (c->nonfinite_scene ? kBlobNonFiniteShading : 0u);
         HIPCHECK(c, hipMemcpyAsync((char*)c->d_blob + offsetof(BlobHeader, flags), &c->hdr.flags, 4, hipMemcpyHostToDevice, c->stream));
@@ -725,8 +728,9 @@ static int device_build_core(crt_ctx* c, DevBuild& B, std::string& err) {
     rc = grow(pn, cap_nodes, (size_t)n * sizeof(Node8)); c->d_lbvh_nodes = (Node8*)pn; c->lbvh_nodes_cap = cap_nodes / sizeof(Node8); if (rc) return rc;
     rc = grow(ps, cap_s2s, (size_t)n * 4); c->d_lbvh_s2s = (uint32_t*)ps; c->lbvh_s2s_cap = cap_s2s / 4; if (rc) return rc;
     uint32_t nnodes = 0, depth = 0;
-    float root_box[6];
-    rc = lbvh_build(c->d_lbvh, B.prims, n, c->d_lbvh_nodes, n, c->d_lbvh_s2s, &nnodes, &depth, root_box, B.s, &err);
+    float root_box[6], exact_box[6];
+    const float origin_bound = c->origin_bound_scene;
+    rc = lbvh_build(c->d_lbvh, B.prims, n, origin_bound, c->d_lbvh_nodes, n, c->d_lbvh_s2s, &nnodes, &depth, root_box, exact_box, B.s, &err);
     if (rc) return rc;
     /* tie-break ranks: the reference's own leaf order, replayed on the device (refrank.hip).  Where its recursion does not
      * terminate (more than 64 primitives sharing a centroid coordinate on the split axis) ties resolve by scene index */
@@ -735,14 +739,14 @@ static int device_build_core(crt_ctx* c, DevBuild& B, std::string& err) {
         if ((rc = grow(c->d_refrank, c->refrank_cap, refrank_scratch_bytes(n)))) return rc;
         rc = grow(pr, cap_rout, (size_t)n * 4); c->d_refrank_out = (uint32_t*)pr; c->refrank_out_cap = cap_rout / 4; if (rc) return rc;
         std::string rerr;
-        rc = refrank_build(c->d_refrank, B.prims, n, root_box, c->d_refrank_out, &B.levels, B.s, &rerr);
+        rc = refrank_build(c->d_refrank, B.prims, n, exact_box, c->d_refrank_out, &B.levels, B.s, &rerr);
         if (rc == CRT_OK) B.rank_valid = true;
         else if (rc != CRT_ERR_BUILD) { err = rerr; return rc; }
     }
     BlobHeader h{};
     h.magic = kBlobMagic; h.version = kBlobVersion;
     h.nprims = n; h.nnodes = nnodes; h.nmats = (uint32_t)c->mats.size(); h.flags = c->nonfinite_scene ? kBlobNonFiniteShading : 0u;
-    h.depth = depth; h.mode = CRT_BVH_WIDE;
+    h.depth = depth; h.mode = CRT_BVH_WIDE; h.origin_bound = origin_bound;
     memcpy(h.root_box, root_box, sizeof h.root_box);
     layout_blob(h);
     if (h.total_bytes > B.blob_cap || !B.blob) {
@@ -835,7 +839,7 @@ int crt_bvh_build(crt_ctx* c, int mode) {
     BlobHeader h{};
     h.magic = kBlobMagic; h.version = kBlobVersion;
     h.nprims = (uint32_t)n; h.nnodes = (uint32_t)c->bvh.node_count(); h.nmats = (uint32_t)c->mats.size(); h.flags = c->nonfinite_scene ? kBlobNonFiniteShading : 0u;
-    h.depth = (uint32_t)c->bvh.depth; h.mode = (uint32_t)mode;
+    h.depth = (uint32_t)c->bvh.depth; h.mode = (uint32_t)mode; h.origin_bound = mode == CRT_BVH_WIDE ? c->bvh.origin_bound : 0.f;
     memcpy(h.root_box, c->bvh.root_box, sizeof h.root_box);
     layout_blob(h);
     if (h.total_bytes > c->blob_cap || !c->d_blob) {
@@ -1184,7 +1188,7 @@ int crt_render_submit(crt_ctx* c, int slot, const crt_camera* cam, const crt_par
         const bool wide = c->hdr.mode == CRT_BVH_WIDE;
         auto common = [&](TraceArgs& t, int launch) {
             t.sv = sv; t.next = ctr + kCtrFetch0 + launch * 8 * kFetchStride;
-            t.hitSlot = f.hitSlot; t.hitT = f.hitT; t.shflag = f.shflag; t.scene_abs = sabs;
+            t.hitSlot = f.hitSlot; t.hitT = f.hitT; t.shflag = f.shflag; t.scene_abs = sabs; t.origin_bound = c->hdr.origin_bound;
             t.ovf = ovf; t.ovf_depth = c->ovf_depth; t.counters = c->d_testctr; t.status = c->d_status; t.block = c->trace_block;
         };
         for (int b = 0; b < p->bounces; b++) {
@@ -1262,7 +1266,7 @@ int crt_render_submit(crt_ctx* c, int slot, const crt_camera* cam, const crt_par
                                 c->d_area_table, f.sum};
         memcpy(key.ptrs, ptrs, sizeof ptrs);
         key.nnodes = c->hdr.nnodes; key.nprims = c->hdr.nprims; key.nmats = c->hdr.nmats; key.depth = c->hdr.depth; key.mode = c->hdr.mode;
-        key.counting = c->counting; key.capture = c->capture; key.grid = gb; key.ovf_depth = c->ovf_depth; key.block = c->trace_block; key.keep_zero = fp.keep_zero; key.scene_abs = sabs;
+        key.counting = c->counting; key.capture = c->capture; key.grid = gb; key.ovf_depth = c->ovf_depth; key.block = c->trace_block; key.keep_zero = fp.keep_zero; key.scene_abs = sabs; key.origin_bound = c->hdr.origin_bound;
         if (!f.graph_exec || memcmp(&key, &f.graph_key, sizeof key) != 0) {
             if (f.graph_exec) { hipGraphExecDestroy(f.graph_exec); f.graph_exec = nullptr; }
             if (f.graph) { hipGraphDestroy(f.graph); f.graph = nullptr; }
@@ -1470,7 +1474,7 @@ static int trace_hook(crt_ctx* c, const float* org_dir, int n, int32_t* prim_out
         launch_pack_rays(d_od, (uint32_t)n, d_o, d_d, shadow_out != nullptr, c->stream);
         TraceArgs ta{};
         ta.sv = view_of(c); ta.rayO = d_o; ta.rayD = d_d; ta.count = d_cnt; ta.next = d_cnt + 64;
-        ta.hitSlot = d_slot; ta.hitT = d_t; ta.shflag = d_flag; ta.scene_abs = c->scene_abs;
+        ta.hitSlot = d_slot; ta.hitT = d_t; ta.shflag = d_flag; ta.scene_abs = c->scene_abs; ta.origin_bound = c->hdr.origin_bound;
         ta.ovf = c->d_ovf; ta.ovf_depth = c->ovf_depth; ta.counters = c->d_testctr; ta.status = c->d_status; ta.block = c->trace_block;
         if (c->counting) TH(hipMemsetAsync(c->d_testctr, 0, 32 * sizeof(unsigned long long), c->stream));
         if (shadow_out && c->hdr.mode == CRT_BVH_WIDE) {      /* k_trace8 takes shadow rays in its second queue */

@@ -12,6 +12,7 @@ struct TraceView {
     int device;
     bool built, wide;
     float scene_abs;
+    float origin_bound;                      /* BlobHeader::origin_bound */
     uint32_t* ovf; int32_t ovf_depth;        /* sized by crt_bvh_build / crt_blob_import_device, never by a trace call */
     unsigned long long* counters;
     uint32_t* status;                        /* device error word */

@@ -140,6 +140,8 @@ struct TraceArgs {
     int32_t* hitSlot; float* hitT;           /* NEAREST outputs */
     uint8_t* shflag;                         /* SHADOW output, indexed by the target in rayO.w */
     float scene_abs;             /* max |coordinate| of the root box: scales the slab-test pad */
+    float origin_bound;          /* k_trace8: the |ray origin| the tree's sphere boxes are padded for (BlobHeader::origin_bound); a ray from
+                                  * further out widens its own pad (layout.h sphere_box_half) */
     uint32_t* ovf; int32_t ovf_depth;        /* per-thread stack overflow area in HBM: ovf_depth entries of 4 B (k_trace) or 8 B (k_trace8) */
     unsigned long long* counters;            /* [0]=box [1]=tri [2]=sph tests [3]=node visits, when counting */
     uint32_t* status;            /* device error word: bit0 = stack overflow beyond ovf, bit1 = node not quantisable */
@@ -167,8 +169,10 @@ void launch_sort_rays(const float4* rayO, const uint32_t* count, uint32_t cap, c
 /* device-side build of the wide tree (lbvh.hip): scratch sized by lbvh_scratch_bytes(n); nodes_out holds up to
  * node_cap (>= n) Node8 records, slot_to_scene n words; the node count and depth come back to the host */
 size_t lbvh_scratch_bytes(uint32_t n);
-int lbvh_build(void* scratch, const crt_prim* d_prims, uint32_t n, Node8* nodes_out, uint32_t node_cap, uint32_t* slot_to_scene,
-               uint32_t* h_nnodes, uint32_t* h_depth, float root_box[6], hipStream_t s, std::string* err);
+/* root_box: of the tree (sphere boxes padded for origin_bound, layout.h sphere_box_half); exact_box: of the primitives as they
+ * are -- the scene box the reference's own split starts from (refrank_build) */
+int lbvh_build(void* scratch, const crt_prim* d_prims, uint32_t n, float origin_bound, Node8* nodes_out, uint32_t node_cap, uint32_t* slot_to_scene,
+               uint32_t* h_nnodes, uint32_t* h_depth, float root_box[6], float exact_box[6], hipStream_t s, std::string* err);
 /* rank_of_scene: the reference's leaf-order rank of every primitive (refrank.hip), or null = ties resolve by scene index */
 void launch_lbvh_maps(const uint32_t* slot_to_scene, const uint32_t* rank_of_scene, uint32_t n, uint32_t* sidx, uint32_t* slot_of, uint32_t* rank, hipStream_t s);
 /* the reference's centroid-mean partition replayed on the device (refrank.hip): rank_of_scene[i] = position of primitive i in
@@ -183,8 +187,8 @@ void launch_pack_prims(const crt_prim* d_prims, const uint32_t* d_matid, const u
                        Geom* geom, Shade* shade, hipStream_t s);
 void launch_refit(Node4* nodes, uint32_t nnodes, const Geom* geom, uint32_t* arrive, float* root_box, int grow_only,
                   hipStream_t s);
-void launch_refit8(Node8* nodes, uint32_t nnodes, const Geom* geom, uint32_t* arrive, float* root_box, int grow_only,
-                   hipStream_t s);
+void launch_refit8(Node8* nodes, uint32_t nnodes, const Geom* geom, float origin_bound, uint32_t* arrive, float* root_box, int grow_only,
+                   hipStream_t s);      /* origin_bound: BlobHeader::origin_bound, sphere boxes are padded for it */
 void launch_slots_to_scene(const int32_t* slots, const uint32_t* sidx, int32_t* out, uint32_t n, hipStream_t s);
 void launch_powf_probe(const float* x, const float* y, uint32_t n, float* out, hipStream_t s);
 void launch_pack_rays(const float* org_dir, uint32_t n, float4* rayO, float4* rayD, bool shadow, hipStream_t s);

@@ -915,10 +915,12 @@ __global__ CRT_TRACE8_BOUNDS void k_trace8(TraceArgs A) {
                 if (!(fabsf(d.y) > 1e-20f)) ry = copysignf(1e20f, d.y);
                 if (!(fabsf(d.z) > 1e-20f)) rz = copysignf(1e20f, d.z);
                 ix = rx; iy = ry; iz = rz;
-                /* boxes are conservative already; the pad covers the rounding of the plane arithmetic */
-                const float px = 1e-3f + 1e-6f * (fabsf(o.x) + A.scene_abs);
-                const float py = 1e-3f + 1e-6f * (fabsf(o.y) + A.scene_abs);
-                const float pz = 1e-3f + 1e-6f * (fabsf(o.z) + A.scene_abs);
+                /* boxes are conservative already; the pad covers the rounding of the plane arithmetic.  A ray that starts further out
+                 * than the sphere boxes were padded for (layout.h sphere_box_half) carries the rest of that pad itself */
+                const float far_out = kSphereNoiseSqrtK * fmaxf(__builtin_amdgcn_sqrtf(o.x * o.x + o.y * o.y + o.z * o.z) * 1.00001f - A.origin_bound, 0.f);      /* v_sqrt_f32: 1 ulp */
+                const float px = 1e-3f + 1e-6f * (fabsf(o.x) + A.scene_abs) + far_out;
+                const float py = 1e-3f + 1e-6f * (fabsf(o.y) + A.scene_abs) + far_out;
+                const float pz = 1e-3f + 1e-6f * (fabsf(o.z) + A.scene_abs) + far_out;
                 const bool ngx = ix < 0.f, ngy = iy < 0.f, ngz = iz < 0.f;
                 /* near plane: lo row shifted by -pad for a positive direction, hi row by +pad for a negative one */
                 anx = (ngx ? o.x - px : o.x + px) * ix; afx = (ngx ? o.x + px : o.x - px) * ix;
@@ -1869,7 +1871,7 @@ void launch_animate(crt_prim* d_prims, uint32_t n, const AnimParam& a, hipStream
  * "boxes never shrink" rule; min/max are exact, so the result is order independent.
  * ------------------------------------------------------------------------------------------ */
 template <class N>
-__global__ __launch_bounds__(256) void k_refit_leaves(N* nodes, uint32_t nnodes, const Geom* geom, int grow_only) {
+__global__ __launch_bounds__(256) void k_refit_leaves(N* nodes, uint32_t nnodes, const Geom* geom, float origin_bound, int grow_only) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= nnodes * (uint32_t)N::W) return;
     N& nd = nodes[id / (uint32_t)N::W];
@@ -1884,7 +1886,9 @@ __global__ __launch_bounds__(256) void k_refit_leaves(N* nodes, uint32_t nnodes,
         const GeomRec g = load_geom(geom, p);
         if (is_sphere(g)) {
             const float c[3] = {g.a.x, g.a.y, g.a.z};
-            for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], c[a] - g.a.w); hi[a] = fmaxf(hi[a], c[a] + g.a.w); }
+            /* the reference topology keeps the reference's boxes (bvh.cu:301-360); the wide tree's hold what the hit predicate can reach */
+            const float hs = N::W == 8 ? sphere_box_half(c[0], c[1], c[2], g.a.w, origin_bound) : g.a.w;
+            for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], c[a] - hs); hi[a] = fmaxf(hi[a], c[a] + hs); }
         } else {
             const float vx[3] = {g.a.x, g.a.w, g.b.z}, vy[3] = {g.a.y, g.b.x, g.b.w}, vz[3] = {g.a.z, g.b.y, g.c.x};
             for (int q = 0; q < 3; q++) {
@@ -1944,17 +1948,17 @@ __global__ __launch_bounds__(256) void k_refit_up(N* nodes, uint32_t nnodes, uin
 }
 
 template <class N>
-static void launch_refit_t(N* nodes, uint32_t nnodes, const Geom* geom, uint32_t* arrive, float* root_box, int grow_only, hipStream_t s) {
+static void launch_refit_t(N* nodes, uint32_t nnodes, const Geom* geom, float origin_bound, uint32_t* arrive, float* root_box, int grow_only, hipStream_t s) {
     if (nnodes == 0) return;
     (void)hipMemsetAsync(arrive, 0, sizeof(uint32_t) * nnodes, s);
-    hipLaunchKernelGGL((k_refit_leaves<N>), dim3((nnodes * (uint32_t)N::W + 255u) / 256u), dim3(256), 0, s, nodes, nnodes, geom, grow_only);
+    hipLaunchKernelGGL((k_refit_leaves<N>), dim3((nnodes * (uint32_t)N::W + 255u) / 256u), dim3(256), 0, s, nodes, nnodes, geom, origin_bound, grow_only);
     hipLaunchKernelGGL((k_refit_up<N>), dim3((nnodes + 255u) / 256u), dim3(256), 0, s, nodes, nnodes, arrive, root_box, grow_only);
 }
 void launch_refit(Node4* nodes, uint32_t nnodes, const Geom* geom, uint32_t* arrive, float* root_box, int grow_only, hipStream_t s) {
-    launch_refit_t(nodes, nnodes, geom, arrive, root_box, grow_only, s);
+    launch_refit_t(nodes, nnodes, geom, 0.f, arrive, root_box, grow_only, s);
 }
-void launch_refit8(Node8* nodes, uint32_t nnodes, const Geom* geom, uint32_t* arrive, float* root_box, int grow_only, hipStream_t s) {
-    launch_refit_t(nodes, nnodes, geom, arrive, root_box, grow_only, s);
+void launch_refit8(Node8* nodes, uint32_t nnodes, const Geom* geom, float origin_bound, uint32_t* arrive, float* root_box, int grow_only, hipStream_t s) {
+    launch_refit_t(nodes, nnodes, geom, origin_bound, arrive, root_box, grow_only, s);
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -24,11 +24,12 @@
 #ifndef CRT_LAYOUT_H
 #define CRT_LAYOUT_H
 #include <stdint.h>
+#include <math.h>
 
 namespace crt {
 
 constexpr uint32_t kBlobMagic = 0x43525442u;   /* "CRTB" */
-constexpr uint32_t kBlobVersion = 4;
+constexpr uint32_t kBlobVersion = 5;
 constexpr uint32_t kSphereTag = 0x7fc5fe3eu;   /* quiet NaN with a payload no arithmetic produces */
 constexpr uint32_t kChildEmpty = 0xffffffffu;
 constexpr uint32_t kLeafFlag = 0x80000000u;
@@ -42,6 +43,32 @@ __host__ __device__
 #endif
 static inline uint32_t make_leaf(uint32_t start, uint32_t count) {
     return kLeafFlag | ((count - 1u) << kLeafCountShift) | start;
+}
+
+/* Sphere boxes of the wide trees.  intersectSphere (Ray.cu:105-133) evaluates disc = b*b - 4*a*(c.c + o.o - 2 c.o - r*r) in
+ * float; the cancellation inside the bracket leaves an absolute error of up to E = kSphereNoiseK (|c| + |o|)^2 + kSphereNoiseR r^2
+ * in disc / 4a (20 roundings of 2^-24 relative to (|c| + |o|)^2, 5 relative to r^2, counted operation by operation), so the
+ * predicate can report a hit for a ray that passes the centre at any distance up to sqrt(r^2 + E) -- 0.026 for a sphere of radius 0
+ * in the reference's room, which the randomised tests found -- and the hit point it reports lies in that ball.  The reference finds
+ * such a hit whenever the ray crosses the sphere's 64-primitive leaf; a tree with other leaves finds it only if its boxes hold the
+ * ball.  `origin_bound` bounds |o| for rays that start inside the scene or the room (BlobHeader::origin_bound, fixed when the tree is
+ * built); a ray that starts further out widens its own slab pad by sqrt(kSphereNoiseK) * (|o| - origin_bound) instead (k_trace8's
+ * ray set-up).  Returns the half side of the box. */
+constexpr float kSphereNoiseK = 1.25e-6f, kSphereNoiseR = 4e-7f;
+constexpr float kSphereNoiseSqrtK = 1.1181e-3f;        /* >= sqrt(kSphereNoiseK) */
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline float sphere_box_half(float cx, float cy, float cz, float r, float origin_bound) {
+    const float ax = cx < 0.f ? -cx : cx, ay = cy < 0.f ? -cy : cy, az = cz < 0.f ? -cz : cz;
+    const float m = ax > ay ? (ax > az ? ax : az) : (ay > az ? ay : az);
+    /* |c|: the Euclidean norm where its squares cannot overflow, sqrt(3) x the largest coordinate otherwise */
+    const float norm = m < 1e18f ? sqrtf(cx * cx + cy * cy + cz * cz) * 1.000001f : 1.7320509f * m;
+    const float e = kSphereNoiseSqrtK * (norm + origin_bound);
+    const float M = r > e ? r : e;
+    if (!(M > 0.f)) return 0.f;
+    const float rr = r / M, ee = e / M;      /* scaled: r * r overflows for the radii the hostile tests use */
+    return M * sqrtf(rr * rr + ee * ee + kSphereNoiseR * rr * rr) * 1.000001f;
 }
 
 struct alignas(128) Node4 {
@@ -112,7 +139,8 @@ struct BlobHeader {
     float root_box[6];        /* minX,maxX,minY,maxY,minZ,maxZ written by build and refit */
     uint32_t flags;           /* bit 0 (kBlobNonFiniteShading): the scene can shade to a non-finite colour, so paths whose coefficient
                                * is zero are traced on (crt_params.zero_paths); travels with the blob to the ranks that import it */
-    uint32_t pad[7];
+    float origin_bound;       /* wide trees: the |ray origin| their sphere boxes were padded for (sphere_box_half) */
+    uint32_t pad[6];
 };
 constexpr uint32_t kBlobNonFiniteShading = 1u;
 static_assert(sizeof(BlobHeader) % 16 == 0, "header alignment");

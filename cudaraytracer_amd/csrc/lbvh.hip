@@ -34,7 +34,7 @@ struct Scratch {
     uint32_t *parent;             /* [0, n-1): of internal nodes; [n-1, 2n-1): of leaves */
     uint32_t *flags;
     uint32_t *ctr;
-    int32_t *cbox;                /* centre bounds as ordered ints: lo xyz, hi xyz */
+    int32_t *cbox;                /* as ordered ints: [0..5] bounds of the box centres, lo xyz, hi xyz; [6..11] the scene box from the exact primitive boxes */
     QItem *qa, *qb;
     void* sort_tmp; size_t sort_tmp_bytes;
 };
@@ -61,7 +61,7 @@ Scratch carve(void* base, uint32_t n, size_t* total) {
     s.parent = (uint32_t*)take(nn * 8);
     s.flags = (uint32_t*)take(nn * 4);
     s.ctr = (uint32_t*)take(CTR_WORDS * 4);
-    s.cbox = (int32_t*)take(6 * 4);
+    s.cbox = (int32_t*)take(12 * 4);
     s.qa = (QItem*)take(nn * sizeof(QItem)); s.qb = (QItem*)take(nn * sizeof(QItem));
     s.sort_tmp_bytes = sort_temp_bytes(n);
     s.sort_tmp = take(s.sort_tmp_bytes + 256);
@@ -72,22 +72,31 @@ Scratch carve(void* base, uint32_t n, size_t* total) {
 /* order-preserving float <-> int for atomicMin / atomicMax */
 __device__ __forceinline__ int32_t f2ord(float f) { const int32_t i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
 __device__ __forceinline__ float ord2f(int32_t i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+static inline float ord2f_host(int32_t i) { const int32_t b = i >= 0 ? i : i ^ 0x7fffffff; float f; memcpy(&f, &b, 4); return f; }
 
 constexpr int kBoundsPerThread = 4;
-__global__ __launch_bounds__(256) void k_lbvh_bounds(const crt_prim* prims, uint32_t n, float4* plo, float4* phi, int32_t* cbox) {
-    __shared__ float s_red[4][6];
-    float cmin[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, cmax[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+/* plo / phi: the primitive boxes the tree is built from -- a sphere's is padded (layout.h sphere_box_half).  The scene box of the
+ * EXACT primitive boxes is reduced beside the centre bounds: it is the root of the reference's own split, which refrank.hip replays */
+__global__ __launch_bounds__(256) void k_lbvh_bounds(const crt_prim* prims, uint32_t n, float origin_bound, float4* plo, float4* phi, int32_t* cbox) {
+    __shared__ float s_red[4][12];
+    float cmin[6] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
+    float cmax[6] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
     for (int r = 0; r < kBoundsPerThread; r++) {
         const uint32_t i = (blockIdx.x * kBoundsPerThread + r) * blockDim.x + threadIdx.x;
         if (i >= n) break;
         const crt_prim& o = prims[i];
         float lo[3], hi[3];
         if (o.type == 0) {
-            for (int a = 0; a < 3; a++) { lo[a] = o.position[a] - o.radius; hi[a] = o.position[a] + o.radius; }
+            const float hs = sphere_box_half(o.position[0], o.position[1], o.position[2], o.radius, origin_bound);
+            for (int a = 0; a < 3; a++) {
+                cmin[3 + a] = fminf(cmin[3 + a], o.position[a] - o.radius); cmax[3 + a] = fmaxf(cmax[3 + a], o.position[a] + o.radius);
+                lo[a] = o.position[a] - hs; hi[a] = o.position[a] + hs;
+            }
         } else {
             for (int a = 0; a < 3; a++) {
                 lo[a] = fminf(o.v1[a], fminf(o.v2[a], o.v3[a]));
                 hi[a] = fmaxf(o.v1[a], fmaxf(o.v2[a], o.v3[a]));
+                cmin[3 + a] = fminf(cmin[3 + a], lo[a]); cmax[3 + a] = fmaxf(cmax[3 + a], hi[a]);
             }
         }
         plo[i] = make_float4(lo[0], lo[1], lo[2], 0.f);
@@ -99,19 +108,20 @@ __global__ __launch_bounds__(256) void k_lbvh_bounds(const crt_prim* prims, uint
     }
     /* bounds of the box centres: wave reduction, the block's four waves through LDS, then one atomic per block and component
      * (atomics on one address serialise at ~10 ns each: one per wave cost 1 ms for 1M primitives) */
-    for (int a = 0; a < 3; a++)
+    for (int a = 0; a < 6; a++)
         for (int off = 32; off > 0; off >>= 1) {
             cmin[a] = fminf(cmin[a], __shfl_xor(cmin[a], off));
             cmax[a] = fmaxf(cmax[a], __shfl_xor(cmax[a], off));
         }
     const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63u) == 0u) for (int a = 0; a < 3; a++) { s_red[wave][a] = cmin[a]; s_red[wave][3 + a] = cmax[a]; }
+    if ((threadIdx.x & 63u) == 0u) for (int a = 0; a < 6; a++) { s_red[wave][a] = cmin[a]; s_red[wave][6 + a] = cmax[a]; }
     __syncthreads();
-    if (threadIdx.x < 3) {
-        const int a = threadIdx.x;
+    if (threadIdx.x < 6) {
+        const int a = threadIdx.x;          /* 0..2 centre bounds -> cbox[a], cbox[3 + a]; 3..5 exact scene box -> cbox[6 + (a - 3)], cbox[9 + (a - 3)] */
         const float mn = fminf(fminf(s_red[0][a], s_red[1][a]), fminf(s_red[2][a], s_red[3][a]));
-        const float mx = fmaxf(fmaxf(s_red[0][3 + a], s_red[1][3 + a]), fmaxf(s_red[2][3 + a], s_red[3][3 + a]));
-        if (mn <= mx) { atomicMin(&cbox[a], f2ord(mn)); atomicMax(&cbox[3 + a], f2ord(mx)); }
+        const float mx = fmaxf(fmaxf(s_red[0][6 + a], s_red[1][6 + a]), fmaxf(s_red[2][6 + a], s_red[3][6 + a]));
+        const int lo_at = a < 3 ? a : 3 + a, hi_at = a < 3 ? 3 + a : 6 + a;
+        if (mn <= mx) { atomicMin(&cbox[lo_at], f2ord(mn)); atomicMax(&cbox[hi_at], f2ord(mx)); }
     }
 }
 
@@ -371,23 +381,26 @@ void launch_lbvh_maps(const uint32_t* slot_to_scene, const uint32_t* rank_of_sce
     if (n) hipLaunchKernelGGL(k_lbvh_maps, dim3((n + 255u) / 256u), dim3(256), 0, s, slot_to_scene, rank_of_scene, n, sidx, slot_of, rank);
 }
 
-int lbvh_build(void* scratch, const crt_prim* d_prims, uint32_t n, Node8* nodes_out, uint32_t node_cap, uint32_t* slot_to_scene,
-               uint32_t* h_nnodes, uint32_t* h_depth, float root_box[6], hipStream_t s, std::string* err) {
+int lbvh_build(void* scratch, const crt_prim* d_prims, uint32_t n, float origin_bound, Node8* nodes_out, uint32_t node_cap, uint32_t* slot_to_scene,
+               uint32_t* h_nnodes, uint32_t* h_depth, float root_box[6], float exact_box[6], hipStream_t s, std::string* err) {
     if (n == 0 || node_cap == 0) { if (err) *err = "lbvh_build: empty scene"; return CRT_ERR_ARG; }
     Scratch S = carve(scratch, n, nullptr);
     const uint32_t blocks = (n + 255u) / 256u;
     const int32_t big = 0x7f7fffff;       /* ordered int of +FLT_MAX; its negation orders as -FLT_MAX */
-    const int32_t init[6] = {big, big, big, -big, -big, -big};
+    const int32_t init[12] = {big, big, big, -big, -big, -big, big, big, big, -big, -big, -big};
     LB(hipMemcpyAsync(S.cbox, init, sizeof init, hipMemcpyHostToDevice, s));
     LB(hipMemsetAsync(S.ctr, 0, CTR_WORDS * 4, s));
-    hipLaunchKernelGGL(k_lbvh_bounds, dim3((n + 256u * kBoundsPerThread - 1u) / (256u * kBoundsPerThread)), dim3(256), 0, s, d_prims, n, S.plo, S.phi, S.cbox);
+    hipLaunchKernelGGL(k_lbvh_bounds, dim3((n + 256u * kBoundsPerThread - 1u) / (256u * kBoundsPerThread)), dim3(256), 0, s, d_prims, n, origin_bound, S.plo, S.phi, S.cbox);
     if (n == 1) {
         hipLaunchKernelGGL(k_lbvh_single, dim3(1), dim3(1), 0, s, S.plo, S.phi, nodes_out, slot_to_scene);
         float4 lo, hi;
+        int32_t eb[6];
         LB(hipMemcpyAsync(&lo, S.plo, 16, hipMemcpyDeviceToHost, s));
         LB(hipMemcpyAsync(&hi, S.phi, 16, hipMemcpyDeviceToHost, s));
+        LB(hipMemcpyAsync(eb, S.cbox + 6, sizeof eb, hipMemcpyDeviceToHost, s));
         LB(hipStreamSynchronize(s));
         root_box[0] = lo.x; root_box[1] = hi.x; root_box[2] = lo.y; root_box[3] = hi.y; root_box[4] = lo.z; root_box[5] = hi.z;
+        for (int a = 0; a < 3; a++) { exact_box[2 * a] = ord2f_host(eb[a]); exact_box[2 * a + 1] = ord2f_host(eb[3 + a]); }
         *h_nnodes = 1; *h_depth = 1;
         return CRT_OK;
     }
@@ -420,12 +433,15 @@ int lbvh_build(void* scratch, const crt_prim* d_prims, uint32_t n, Node8* nodes_
     LB(hipGetLastError());
     uint32_t h[CTR_WORDS];
     float4 rlo, rhi;
+    int32_t eb[6];
+    LB(hipMemcpyAsync(eb, S.cbox + 6, sizeof eb, hipMemcpyDeviceToHost, s));
     LB(hipMemcpyAsync(h, S.ctr, sizeof h, hipMemcpyDeviceToHost, s));
     LB(hipMemcpyAsync(&rlo, S.ilo, 16, hipMemcpyDeviceToHost, s));
     LB(hipMemcpyAsync(&rhi, S.ihi, 16, hipMemcpyDeviceToHost, s));
     LB(hipStreamSynchronize(s));
     if (level_count != 0 || h[CTR_SLOTS] != n || h[CTR_NODES] > node_cap) { if (err) *err = "lbvh_build: collapse did not place every primitive"; return CRT_ERR_BUILD; }
     root_box[0] = rlo.x; root_box[1] = rhi.x; root_box[2] = rlo.y; root_box[3] = rhi.y; root_box[4] = rlo.z; root_box[5] = rhi.z;
+    for (int a = 0; a < 3; a++) { exact_box[2 * a] = ord2f_host(eb[a]); exact_box[2 * a + 1] = ord2f_host(eb[3 + a]); }
     *h_nnodes = h[CTR_NODES]; *h_depth = h[CTR_DEPTH];
     return CRT_OK;
 }

@@ -94,7 +94,7 @@ extern "C" int crt_trace_noalloc(crt_ctx* c, const float* dev_org_dir, int n, in
     hipLaunchKernelGGL(k_noalloc_pack, dim3(((uint32_t)n + 255u) / 256u), dim3(256), 0, v.stream, dev_org_dir, (uint32_t)n, rayO, rayD, ctr);
     TraceArgs ta{};
     ta.sv = v.sv; ta.rayO = rayO; ta.rayD = rayD; ta.count = ctr; ta.next = ctr + 64;
-    ta.hitSlot = slot; ta.hitT = dev_t_out; ta.shflag = nullptr; ta.scene_abs = v.scene_abs;
+    ta.hitSlot = slot; ta.hitT = dev_t_out; ta.shflag = nullptr; ta.scene_abs = v.scene_abs; ta.origin_bound = v.origin_bound;
     ta.ovf = v.ovf; ta.ovf_depth = v.ovf_depth; ta.counters = v.counters; ta.status = v.status;
     ta.block = v.block;
     launch_trace(ta, TRACE_NEAREST, false, v.wide, v.grid_blocks, v.stream);

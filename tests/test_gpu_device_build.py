@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import orc
+from sphere_pad import sphere_box_half
 
 pytestmark = pytest.mark.gpu
 DEVICE = 2
@@ -27,9 +28,10 @@ def random_rays(n, seed, span=150):
 
 def check_hierarchy(ctx, prims):
     root, boxes, links = ctx.dump()
-    lo = np.where(prims["type"][:, None] == 0, prims["position"] - prims["radius"][:, None],
+    half = sphere_box_half(prims)          # a sphere's box holds what its hit predicate can reach (layout.h sphere_box_half)
+    lo = np.where(prims["type"][:, None] == 0, prims["position"] - half[:, None],
                   np.minimum(np.minimum(prims["v1"], prims["v2"]), prims["v3"]))
-    hi = np.where(prims["type"][:, None] == 0, prims["position"] + prims["radius"][:, None],
+    hi = np.where(prims["type"][:, None] == 0, prims["position"] + half[:, None],
                   np.maximum(np.maximum(prims["v1"], prims["v2"]), prims["v3"]))
     assert np.array_equal(root[0::2], lo.min(axis=0)) and np.array_equal(root[1::2], hi.max(axis=0))
     nleaf, nodes_seen, depth = 0, 0, 0
@@ -172,14 +174,16 @@ def test_device_build_of_tiny_scenes(crt, n):
 
 @pytest.mark.parametrize("mode", [0, DEVICE])
 def test_deep_tree_uses_the_stack_overflow_rows(crt, mode):
-    """exponentially spaced spheres give a chain-like tree deeper than the 14 stack entries kept in LDS:
-    the per-lane overflow rows in HBM take the rest, results unchanged"""
+    """exponentially spaced triangles give a chain-like tree deeper than the 14 stack entries kept in LDS:
+    the per-lane overflow rows in HBM take the rest, results unchanged.  (Until the sphere boxes of the wide trees were padded for
+    their predicate's rounding noise -- layout.h sphere_box_half -- this scene was made of spheres of radius 0.01 x at x = 1.08^k;
+    at 1e10 from the origin that noise is larger than the small ones, their boxes overlap and the tree is shallow.)"""
     n, base = 300, 1.08
-    prims = crt.scene_spheres(n, seed=1)
-    k = np.arange(n)
-    prims["position"][:, 0] = (base ** k).astype(np.float32)
-    prims["position"][:, 1] = 0; prims["position"][:, 2] = 0
-    prims["radius"] = (0.01 * base ** k).astype(np.float32)
+    prims = crt.scene_soup(n, seed=1)
+    x = (base ** np.arange(n)).astype(np.float32)
+    s = (np.float32(0.05) * x).astype(np.float32)
+    zero = np.zeros(n, np.float32)
+    prims["v1"] = np.stack([x, -s, -s], axis=1); prims["v2"] = np.stack([x, s, -s], axis=1); prims["v3"] = np.stack([x, zero, 2 * s], axis=1)
     ctx = crt.Context(0)
     ctx.set_scene(prims); ctx.build(mode)
     sc = orc.Scene(prims); sc.build()

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import orc
+from sphere_pad import sphere_box_half
 
 G = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -162,9 +163,10 @@ def check_wide_hierarchy(crt, prims):
     h = crt.host_bvh(prims, 0)
     boxes, links, s2s = h["boxes"], h["links"], h["slot_to_scene"]
     assert sorted(s2s.tolist()) == list(range(len(prims)))                 # every primitive in exactly one leaf
-    lo = np.where(prims["type"][:, None] == 0, prims["position"] - prims["radius"][:, None],
+    half = sphere_box_half(prims)
+    lo = np.where(prims["type"][:, None] == 0, prims["position"] - half[:, None],
                   np.minimum(np.minimum(prims["v1"], prims["v2"]), prims["v3"]))
-    hi = np.where(prims["type"][:, None] == 0, prims["position"] + prims["radius"][:, None],
+    hi = np.where(prims["type"][:, None] == 0, prims["position"] + half[:, None],
                   np.maximum(np.maximum(prims["v1"], prims["v2"]), prims["v3"]))
     seen = np.zeros(len(prims), bool)
     depth_seen = 0
@@ -184,7 +186,7 @@ def check_wide_hierarchy(crt, prims):
                 idx = s2s[start:start + cnt]
                 assert not seen[idx].any()
                 seen[idx] = True
-                assert np.all(lo[idx] >= b[0::2]) and np.all(hi[idx] <= b[1::2])        # exact, unpadded bounds
+                assert np.all(lo[idx] >= b[0::2]) and np.all(hi[idx] <= b[1::2])        # exact bounds: triangles as they are, spheres with sphere_box_half
                 assert np.array_equal(b[0::2], lo[idx].min(axis=0)) and np.array_equal(b[1::2], hi[idx].max(axis=0))
             else:
                 assert tuple(h["parents"][link]) == (node, k)
