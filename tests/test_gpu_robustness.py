@@ -51,7 +51,7 @@ def compare(crt, prims, rays, what, modes=(0, 2), min_hits=100):
         rel = np.abs(ts_g[hit] - ts_o[hit]) / np.maximum(np.abs(ts_o[hit]), 1e-30)
         print(f"{what} mode={mode}: rays={len(rays)} hits={int((ids_o >= 0).sum())} id_mismatch={int(bad.sum())} "
               f"t_exact={int((ts_g[hit] == ts_o[hit]).sum())}/{int(hit.sum())}")
-        assert bad.sum() <= 2, f"{what} mode={mode}: {int(bad.sum())} id mismatches"
+        assert bad.sum() == 0, f"{what} mode={mode}: {int(bad.sum())} id mismatches"
         assert (rel > T_RTOL).sum() == 0
 
 
