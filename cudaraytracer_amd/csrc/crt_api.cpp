@@ -80,6 +80,8 @@ struct FrameSlot {
 /* one device build (device_build_core): where it runs, what it reads, where the tree goes */
 struct DevBuild {
     hipStream_t s; const crt_prim* prims; bool pack;      /* in: stream, scene to build from, whether to pack geometry too */
+    float origin_bound;                                   /* in: what the sphere boxes are padded for (taken when the build is described: the
+                                                           * asynchronous build runs on a thread of its own while the scene may be updated) */
     void* blob; size_t blob_cap;                          /* in/out: target blob (reallocated when too small) */
     BlobHeader hdr; bool rank_valid; uint32_t levels; double ms;      /* out */
 };
@@ -729,7 +731,7 @@ static int device_build_core(crt_ctx* c, DevBuild& B, std::string& err) {
     rc = grow(ps, cap_s2s, (size_t)n * 4); c->d_lbvh_s2s = (uint32_t*)ps; c->lbvh_s2s_cap = cap_s2s / 4; if (rc) return rc;
     uint32_t nnodes = 0, depth = 0;
     float root_box[6], exact_box[6];
-    const float origin_bound = c->origin_bound_scene;
+    const float origin_bound = B.origin_bound;
     rc = lbvh_build(c->d_lbvh, B.prims, n, origin_bound, c->d_lbvh_nodes, n, c->d_lbvh_s2s, &nnodes, &depth, root_box, exact_box, B.s, &err);
     if (rc) return rc;
     /* tie-break ranks: the reference's own leaf order, replayed on the device (refrank.hip).  Where its recursion does not
@@ -795,7 +797,7 @@ static int adopt_device_tree(crt_ctx* c, const DevBuild& B) {
 static int build_on_device(crt_ctx* c) {
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     DevBuild B{};
-    B.s = c->stream; B.prims = c->d_prims; B.pack = true; B.blob = c->d_blob; B.blob_cap = c->blob_cap;
+    B.s = c->stream; B.prims = c->d_prims; B.pack = true; B.blob = c->d_blob; B.blob_cap = c->blob_cap; B.origin_bound = c->origin_bound_scene;
     std::string err;
     const int rc = device_build_core(c, B, err);
     c->d_blob = B.blob; c->blob_cap = B.blob_cap;          /* the core may have reallocated it even when it failed later */
@@ -914,7 +916,7 @@ int crt_bvh_build_async(crt_ctx* c) {
     HIPCHECK(c, hipStreamWaitEvent(c->stream, c->ev_snap, 0));
     c->async_build = DevBuild{};
     c->async_build.s = c->build_stream; c->async_build.prims = c->d_prims_snap; c->async_build.pack = false;
-    c->async_build.blob = c->d_blob2; c->async_build.blob_cap = c->blob2_cap;
+    c->async_build.blob = c->d_blob2; c->async_build.blob_cap = c->blob2_cap; c->async_build.origin_bound = c->origin_bound_scene;
     c->async_err.clear(); c->async_rc = 0;
     c->dev_rank_valid = false;          /* the rank buffer crt_bvh_reference_order reads is the builder's from here to the swap */
     c->build_state = 1;
