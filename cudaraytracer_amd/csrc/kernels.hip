@@ -1543,6 +1543,10 @@ __global__ CRT_SHADE_BOUNDS void k_shade(FrameParams P, FrameBuffers B, SceneVie
                      * defined here as end of path, colour unchanged */
                     dead = true;
                     if (raytype == 0) B.accum[pix] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    /* k_resolve learns that a path is dead from the first light's flag.  Without lights it would add coefficient * 0 for
+                     * it -- NaN once the coefficient has overflowed (found by the randomised tests: two mirrors of reflectance 1e20,
+                     * then nothing): the coefficient this entry was read from becomes zero, and 0 * 0 leaves the colour as it is */
+                    else if (LP.n == 0) B.coef[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
             if (P.capture) {

@@ -650,6 +650,25 @@ def test_lattice_scenes_rays_through_edges_and_vertices(crt, seed):
         assert np.array_equal(ts_g[same].view(np.uint32), ts_o[same].view(np.uint32)), f"seed {seed} mode {mode}"
 
 
+@pytest.mark.parametrize("nlights", [0, 1])
+def test_paths_that_end_after_their_coefficient_overflowed(crt, nlights):
+    """mirrors of reflectance 1e20 outside the room: after two of them the running coefficient is infinite, and most third rays meet
+    neither an object nor a wall -- end of path, colour unchanged.  Without lights nothing told k_resolve that such a
+    path had ended and it added coefficient * 0 = NaN (found by the soak: seed 29002 of the 960 x 540 family, one pixel)"""
+    prims = crt.scene_spheres(60, seed=11)
+    prims["position"] = (prims["position"] * np.float32(0.3) + np.array([900, 0, 0], np.float32)).astype(np.float32)
+    prims["radius"] = 14.0
+    prims["reflective"] = 1e20
+    prims["objNum"] = np.arange(len(prims), dtype=np.int32)
+    lights = crt.default_lights()[:nlights]
+    cam = np.array([900, 10, 260], np.float32); tgt = np.array([900, 0, 0], np.float32)
+    o, ost, frames = _frame_pair(crt, prims, lights, cam, tgt, 200, 120, 4)
+    assert ost["traversals"] > 200 * 120 * 1.2          # paths do go on after the first mirror
+    for mode, g, rays in frames:
+        assert np.array_equal(g, o["bgr"]), f"{nlights} lights, mode {mode}: {int((g != o['bgr']).any(axis=2).sum())} pixels differ"
+    assert (o["bgr"] > 0).any()
+
+
 @pytest.mark.parametrize("seed", _seeds(8))
 def test_spheres_smaller_than_their_predicate_s_rounding_noise(crt, seed):
     """intersectSphere (Ray.cu:105-133) computes its discriminant from c.c + o.o - 2 c.o - r*r in float: a sphere of radius 0 .. 0.1 a
