@@ -130,7 +130,7 @@ def compare_with_oracle_tree(crt, prims):
         rec(0, h["root"], 0)
 
 
-@pytest.mark.parametrize("seed", list(range(24)))
+@pytest.mark.parametrize("seed", [int(os.environ.get("CRT_FUZZ_SEED_BASE", "0")) + k for k in range(24)])
 def test_random_scenes_build_the_oracle_s_tree(crt, seed):
     """the generators of tests/test_gpu_fuzz.py (triangles and spheres interleaved, stretched, on a lattice with many equal
     centroid coordinates and boxes of zero thickness): newBuild/constructTree restated in the product gives the oracle's tree,

@@ -81,7 +81,7 @@ def run_reference(path, tmp):
 
 def test_random_obj_files_load_as_the_reference_loads_them(tmp_path):
     import cudaraytracer_amd as crt
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + int(os.environ.get("CRT_FUZZ_SEED_BASE", "0")))      # a soak: any other base draws other files
     loaded = failed = 0
     for k in range(300):
         text = random_obj(rng)
