@@ -191,7 +191,10 @@ int crt_bvh_free(crt_ctx*);
 int crt_bvh_reference_order(crt_ctx*, int32_t* rank_out, int n);
 /* Node boxes after build/refit, for parity checks of the refit kernel: 6 floats per stored child
  * box in node order (minX,maxX,minY,maxY,minZ,maxZ), plus the root box first.  Every node is
- * dumped with CRT_BVH_DUMP_WIDTH child entries (the reference topology uses the first two). */
+ * dumped with CRT_BVH_DUMP_WIDTH child entries (the reference topology uses the first two).
+ * The reference topology holds the reference's boxes (bvh.cu:70-129, 301-360).  In the wide trees a triangle's box is
+ * exact and a sphere's is the cube around the ball that intersectSphere's float arithmetic can report a hit in (Ray.cu:110-113
+ * cancels: a little more than the sphere, and more than that for spheres much smaller than their distance from the origin). */
 #define CRT_BVH_DUMP_WIDTH 8
 int crt_bvh_dump(crt_ctx*, int32_t* nnodes, float* root_box6, float* child_boxes /* nnodes*8*6 */,
                  uint32_t* child_links /* nnodes*8 */, int cap_nodes);
