@@ -79,6 +79,7 @@ struct orc_scene {
     std::vector<Node*> all;     /* ownership; the reference's freeTree is buggy (bvh.cu:274-286) */
     int nNum = 1;               /* bvh.cu:11 */
     Counters stats;
+    bool all_boxes_hit = false; /* G3 probe (orc_set_all_boxes_hit): bvhTraverse as if boundingBoxIntersection never said no */
 };
 
 namespace {
@@ -175,7 +176,7 @@ void bvh_traverse(const orc_scene* sc, const ov3& position, const ov3& direction
                   float& minT, int& obj, ov3& minTnormal, ov3& minTintersection, Counters& k) {
     if (cur->isleaf) {
         k.box++;
-        if (bbox_hit(position, direction, cur->minX, cur->maxX, cur->minY, cur->maxY, cur->minZ, cur->maxZ)) {
+        if (sc->all_boxes_hit || bbox_hit(position, direction, cur->minX, cur->maxX, cur->minY, cur->maxY, cur->minZ, cur->maxZ)) {
             for (int i = 0; i < cur->numObjs; i++) {
                 const orc_prim& p = sc->prims[cur->objs[i]];
                 if (p.type == 0) {
@@ -202,10 +203,10 @@ void bvh_traverse(const orc_scene* sc, const ov3& position, const ov3& direction
     } else {
         const Node* l = cur->left; const Node* r = cur->right;
         k.box++;
-        if (bbox_hit(position, direction, l->minX, l->maxX, l->minY, l->maxY, l->minZ, l->maxZ))
+        if (sc->all_boxes_hit || bbox_hit(position, direction, l->minX, l->maxX, l->minY, l->maxY, l->minZ, l->maxZ))
             bvh_traverse(sc, position, direction, l, intersect, minT, obj, minTnormal, minTintersection, k);
         k.box++;
-        if (bbox_hit(position, direction, r->minX, r->maxX, r->minY, r->maxY, r->minZ, r->maxZ))
+        if (sc->all_boxes_hit || bbox_hit(position, direction, r->minX, r->maxX, r->minY, r->maxY, r->minZ, r->maxZ))
             bvh_traverse(sc, position, direction, r, intersect, minT, obj, minTnormal, minTintersection, k);
     }
 }
@@ -919,6 +920,10 @@ void orc_stats_get(orc_scene* s, orc_stats* o) {
     o->sph_tests = s->stats.sph; o->live_traversals = s->stats.live;
 }
 void orc_stats_reset(orc_scene* s) { s->stats = Counters(); }
+/* G3 probe: the reference's traversal with every box test answered "hit" -- its own leaves in its own order, so
+ * exact-t ties resolve as in the reference, but none of the false negatives of its slab test (Ray.cu:54-104: 0 * inf for a ray
+ * inside the plane of a box of zero thickness).  What a pixel or ray "should" be when the reference disagrees with itself. */
+void orc_set_all_boxes_hit(orc_scene* s, int on) { s->all_boxes_hit = on != 0; }
 
 /* objloader.cpp:20-112: "v", "vn", "f a b c" only; the vertex index doubles as normal index;
  * other tokens eat the line.  Missing file returns -1 (the reference blocks on getchar()). */

@@ -114,6 +114,7 @@ void orc_area_table(float* out3, int n);                   /* n <= 1024 entries 
 void orc_primary_rays(const float cam[3], const float target[3], int width, int height, float* rays6);
 void orc_stats_get(orc_scene*, orc_stats* out);
 void orc_stats_reset(orc_scene*);
+void orc_set_all_boxes_hit(orc_scene*, int on);      /* G3 probe: bvhTraverse without the false negatives of its box test */
 
 /* ---- vec3 probe (pinned against vendored GLM by oracle/ref_driver.cpp) ---- */
 #define ORC_PROBE_W 32

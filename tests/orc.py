@@ -70,7 +70,7 @@ def lib():
         for name, args in {
             "orc_scene_get": [vp, vp], "orc_scene_set": [vp, vp], "orc_refit": [vp], "orc_animate": [vp],
             "orc_trace": [vp, vp, i, vp, vp, vp, vp, i], "orc_trace_brute": [vp, vp, i, vp, vp, i],
-            "orc_primary_rays": [vp, vp, i, i, vp], "orc_stats_get": [vp, vp], "orc_stats_reset": [vp],
+            "orc_primary_rays": [vp, vp, i, i, vp], "orc_stats_get": [vp, vp], "orc_stats_reset": [vp], "orc_set_all_boxes_hit": [vp, i],
             "orc_math_probe": [vp, i, vp], "orc_area_table": [vp, i], "orc_powf": [vp, vp, i, vp],
         }.items():
             getattr(L, name).restype = None
@@ -204,6 +204,11 @@ class Scene:
         pts = np.zeros((n, 3), np.float32) if with_geometry else None
         lib().orc_trace(self.h, _p(rays6), n, _p(ids), _p(ts), _p(nrm), _p(pts), nthreads)
         return (ids, ts, nrm, pts) if with_geometry else (ids, ts)
+
+    def all_boxes_hit(self, on=True):
+        """G3 probe: the reference's traversal with every box test answered "hit" (its leaves, its order, none of the false
+        negatives of its slab test)"""
+        lib().orc_set_all_boxes_hit(self.h, 1 if on else 0)
 
     def trace_brute(self, rays6, nthreads=8):
         rays6 = np.ascontiguousarray(rays6, np.float32).reshape(-1, 6)

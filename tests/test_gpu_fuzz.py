@@ -461,6 +461,26 @@ def _frame_pair(crt, prims, lights, cam, tgt, w, h, bounces, modes=(0, 1, 2), **
     return o, ost, out
 
 
+def _only_g3_pixels_differ(g, o, prims, lights, cam, tgt, w, h, bounces, what, limit=8, **kw):
+    """SURVEY 9.1 G3 in a frame: the reference's slab test (Ray.cu:54-104) computes 0 * inf for a ray that runs inside the plane
+    of a box of zero thickness and rejects the box, with it a primitive that its own loop over all primitives hits.  A pixel
+    that differs from the oracle's frame is accepted only if it equals the frame the oracle renders with every box test answered
+    "hit" (orc.Scene.all_boxes_hit: the reference's leaves in the reference's order, so ties resolve alike, without those false
+    negatives) -- the HIP path's padded test is conservative and sees what that frame sees.  At most `limit` such pixels."""
+    bad = (g != o["bgr"]).any(axis=2)
+    if not bad.any():
+        return
+    sc = orc.Scene(prims)
+    try:
+        sc.build(); sc.all_boxes_hit(True)
+        ob = sc.render(lights, cam, tgt, w, h, bounces, nthreads=16, area_samples=kw.get("area_samples", 30), spp=kw.get("spp", 1))
+    finally:
+        sc.close()
+    unexplained = int((g[bad] != ob["bgr"][bad]).any(axis=1).sum())
+    print(f"{what}: {int(bad.sum())} pixels differ from the reference's tree, {unexplained} of them also from its traversal without box false-negatives")
+    assert unexplained == 0 and bad.sum() <= limit, f"{what}: {int(bad.sum())} pixels differ, {unexplained} not explained by G3"
+
+
 @pytest.mark.parametrize("nprims", [1, 2, 3, 4, 5, 8, 9, 33, 63, 64, 65, 66, 128, 129, 513])
 def test_primitive_counts_around_the_leaf_and_node_limits(crt, nprims):
     """1 .. 513 primitives: a root that is a leaf (Ray.cu:186-188, <= 64 primitives on the reference topology), the first split at
@@ -608,7 +628,7 @@ def test_lattice_scenes_rays_through_edges_and_vertices(crt, seed):
     w, h = int(rng.choice([64, 128])), int(rng.choice([32, 64]))
     o, ost, frames = _frame_pair(crt, prims, lights, cam, tgt, w, h, 3)
     for mode, g, rays in frames:
-        assert np.array_equal(g, o["bgr"]), f"seed {seed} mode {mode}: {int((g != o['bgr']).any(axis=2).sum())} pixels differ"
+        _only_g3_pixels_differ(g, o, prims, lights, cam, tgt, w, h, 3, f"seed {seed} mode {mode}")
     n = 100000
     a = (rng.integers(-14, 15, (n, 3)) * 8).astype(np.float32)
     b = (rng.integers(-14, 15, (n, 3)) * 8).astype(np.float32)
@@ -758,16 +778,18 @@ def test_random_scenes_at_frame_sizes_that_fill_the_chip(crt, seed):
     the tail that small frames live in): a random scene, a hostile one, a lattice one per seed"""
     rng = np.random.default_rng(23000 + seed)
     w, h, bounces = 960, 540, 3
-    scenes = [("random", random_scene(crt, rng)), ("hostile", hostile_scene(crt, rng)[0])]
-    for _ in range(20):
-        p = lattice_scene(crt, rng)
-        sc = orc.Scene(p)
-        try:
-            sc.build(); scenes.append(("lattice", p)); break
-        except RuntimeError:
-            pass
-        finally:
-            sc.close()
+    scenes = []
+    for name, draw in (("random", lambda: random_scene(crt, rng)), ("hostile", lambda: hostile_scene(crt, rng)[0]), ("lattice", lambda: lattice_scene(crt, rng))):
+        for _ in range(20):          # a draw the reference's builder does not terminate on (tests/test_host_layer.py) is drawn again
+            p = draw()
+            sc = orc.Scene(p)
+            try:
+                sc.build(); scenes.append((name, p)); break
+            except RuntimeError:
+                pass
+            finally:
+                sc.close()
+    assert len(scenes) == 3
     for name, prims in scenes:
         lights = random_lights(crt, rng)
         cam = (rng.integers(-14, 15, 3) * 8).astype(np.float32) if name == "lattice" else rng.uniform(-150, 150, 3).astype(np.float32)
@@ -778,7 +800,10 @@ def test_random_scenes_at_frame_sizes_that_fill_the_chip(crt, seed):
         for mode, g, rays in frames:
             nbad = int((g != o["bgr"]).any(axis=2).sum())
             print(f"seed {seed} {name} mode {mode}: {len(prims)} prims, {len(lights)} lights, rays={rays} oracle={ost['traversals']} live={ost['live_traversals']} differing pixels={nbad}")
-            assert nbad == 0, f"seed {seed} {name} mode {mode}"
+            if name == "lattice":
+                _only_g3_pixels_differ(g, o, prims, lights, cam, tgt, w, h, bounces, f"seed {seed} {name} mode {mode}", area_samples=4)
+            else:
+                assert nbad == 0, f"seed {seed} {name} mode {mode}"
             assert rays in (ost["traversals"], ost["live_traversals"])
 
 
