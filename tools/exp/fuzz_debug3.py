@@ -48,6 +48,10 @@ for name, prims in scenes:
                 for i in (ig, o['ids'][b][pix]):
                     if i >= 0:
                         print("      prim", i, {k: prims[i][k] for k in ("type", "position", "radius", "v1", "v2", "v3", "reflective")})
+        if len(ys):
+            y, x = ys[0], xs[0]
+            pr = orc.primary_rays(cam, tgt, w, h).reshape(h * w, 6)[y * w + x].reshape(1, 6)
+            print("  primary ray", pr[0], "oracle tree", sc.trace(pr), "oracle brute", sc.trace_brute(pr, nthreads=1), "gpu", ctx.trace(pr))
         ctx.close()
     sc.close()
     # which light: the same frames with one light at a time, mode 0 against mode 2
