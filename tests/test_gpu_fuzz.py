@@ -279,7 +279,11 @@ def test_random_animation_loop_on_frame_slots_equals_the_oracle(crt, seed):
     """the reference's loop (main.cu:534-573: move, refit or rebuild, render) with every choice drawn from the seed: tight or
     grow-only refit, host / device / asynchronous rebuild, host-side or device-side animation step, the frame rendered
     synchronously or submitted on one of the frame slots and collected up to three steps later -- after the scene has moved on.
-    Every frame must be the oracle's frame of the scene as it was when the frame was submitted."""
+    Every frame must be the oracle's frame of the scene as it was when the frame was submitted.
+    A rebuild is the reference's constructTree on the moved scene: the leaf order that decides exact-t ties (Ray.cu:199,216) is
+    the new tree's from then on, so the oracle rebuilds where the context does -- and for an asynchronous build a second oracle
+    scene is built from the snapshot and takes over at the swap (one frame in some 20,000 of the soak has such a tie: two triangles
+    sharing an edge, a primary ray through it)."""
     rng = np.random.default_rng(9000 + seed)
     prims = random_scene(crt, rng)
     n = len(prims)
@@ -304,6 +308,7 @@ def test_random_animation_loop_on_frame_slots_equals_the_oracle(crt, seed):
     pending = {}          # slot -> (step it was submitted at, the oracle's frame of that step)
     host = prims.copy()
     log = []
+    sc_next = None        # the reference's tree of the snapshot an asynchronous build is working on
 
     def collect(slot):
         step0, want = pending.pop(slot)
@@ -331,19 +336,37 @@ def test_random_animation_loop_on_frame_slots_equals_the_oracle(crt, seed):
             kind = int(rng.choice([0, 0, 0, 1, 2, 3, 4]))
             if building:
                 kind = 5 if rng.integers(0, 2) else 0
+            rebuilt = adopted = False
             if kind == 0: ctx.refit(False)
             elif kind == 1: ctx.refit(True)
-            elif kind == 2: ctx.build(2)
+            elif kind == 2: ctx.build(2); rebuilt = True
             elif kind == 3:
                 for s in list(pending): collect(s)          # crt_scene_set waits for the frames in flight itself; collect them first so their buffers are compared
-                ctx.set_scene(host); ctx.build(0)
+                ctx.set_scene(host); ctx.build(0); rebuilt = True
             elif kind == 4:
                 ctx.build_async(); building = True; ctx.refit(False)
+                sc_next = orc.Scene(host)
+                try:
+                    sc_next.build()
+                except RuntimeError:          # the reference cannot build the moved scene: no oracle for what follows
+                    print(f"seed {seed}: the reference's builder does not terminate on the scene of step {step}; stopped there")
+                    ctx.swap(wait=True)
+                    break
             elif kind == 5:
-                if ctx.swap(wait=True): building = False
+                if ctx.swap(wait=True): building = False; adopted = True
                 else: ctx.refit(False)
             log.append((step, "dev" if on_device else "host", kind))
-            sc.refit()
+            if rebuilt:
+                try:
+                    sc.build()
+                except RuntimeError:
+                    print(f"seed {seed}: the reference's builder does not terminate on the scene of step {step}; stopped there")
+                    break
+            elif adopted:
+                sc_next.set_prims(host); sc_next.refit()
+                sc.close(); sc = sc_next; sc_next = None
+            else:
+                sc.refit()
             # ---- render
             want = sc.render(lights, cam, tgt, w, h, bounces, nthreads=16)["bgr"]
             slot = int(rng.integers(0, 4))
@@ -362,6 +385,7 @@ def test_random_animation_loop_on_frame_slots_equals_the_oracle(crt, seed):
         assert ctx.get_scene().tobytes() == host.tobytes()
     finally:
         ctx.close(); sc.close()
+        if sc_next is not None: sc_next.close()
         for q in bufs:
             hip.hipFree(C.c_void_p(q))
 
