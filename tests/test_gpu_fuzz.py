@@ -31,7 +31,7 @@ def crt():
 def _draw_buildable(draw, scene_of=lambda r: r):
     """a draw the reference's builder terminates on: its split runs away when more than 64 primitives share a centroid coordinate
     on the axis it picks (tests/test_host_layer.py), which one draw in a few thousand does; such a draw has no oracle"""
-    for _ in range(20):
+    for _ in range(200):
         r = draw()
         sc = orc.Scene(scene_of(r))
         try:
@@ -41,7 +41,7 @@ def _draw_buildable(draw, scene_of=lambda r: r):
             pass
         finally:
             sc.close()
-    pytest.fail("no scene the reference's builder terminates on in 20 draws")
+    pytest.fail("no scene the reference's builder terminates on in 200 draws")
 
 
 def random_scene(crt, rng):
@@ -648,7 +648,7 @@ def test_lattice_scenes_rays_through_edges_and_vertices(crt, seed):
     and along axis-aligned faces (grazing hits; zero direction components, boxes of zero thickness).  The traced
     rays themselves are compared too, through the parity hook: 100 k rays between random lattice points."""
     rng = np.random.default_rng(17000 + seed)
-    for _ in range(20):          # the reference's builder recurses forever on some of these (> 64 equal centroid coordinates, tests/test_host_layer.py)
+    for _ in range(200):          # the reference's builder recurses forever on some of these (> 64 equal centroid coordinates, tests/test_host_layer.py)
         prims = lattice_scene(crt, rng)
         sc = orc.Scene(prims)
         try:
@@ -788,7 +788,7 @@ def test_cameras_inside_spheres_and_arbitrary_vertex_normals(crt, seed):
     and triangles whose vertex normals have nothing to do with their plane or with unit length (the shading normal is
     normalize of their mix, Ray.cu:168-172)"""
     rng = np.random.default_rng(19000 + seed)
-    for _ in range(20):
+    for _ in range(200):
         prims = random_scene(crt, rng)
         n = len(prims)
         for f in ("v1Norm", "v2Norm", "v3Norm"):
@@ -810,7 +810,7 @@ def test_cameras_inside_spheres_and_arbitrary_vertex_normals(crt, seed):
         except RuntimeError:          # the reference's builder recurses forever on this draw (tests/test_host_layer.py): draw again
             continue
     else:
-        pytest.fail("no scene the reference's builder terminates on in 20 draws")
+        pytest.fail("no scene the reference's builder terminates on in 200 draws")
     for mode, g, rays in frames:
         assert np.array_equal(g, o["bgr"]), f"seed {seed} mode {mode}: {int((g != o['bgr']).any(axis=2).sum())} pixels differ"
         assert rays == ost["traversals"]          # the arbitrary normals are not on one side of their triangles: zero-coefficient paths are traced on
@@ -824,7 +824,7 @@ def test_random_scenes_at_frame_sizes_that_fill_the_chip(crt, seed):
     w, h, bounces = 960, 540, 3
     scenes = []
     for name, draw in (("random", lambda: random_scene(crt, rng)), ("hostile", lambda: hostile_scene(crt, rng)[0]), ("lattice", lambda: lattice_scene(crt, rng))):
-        for _ in range(20):          # a draw the reference's builder does not terminate on (tests/test_host_layer.py) is drawn again
+        for _ in range(200):          # a draw the reference's builder does not terminate on (tests/test_host_layer.py) is drawn again
             p = draw()
             sc = orc.Scene(p)
             try:
